@@ -1,0 +1,144 @@
+/*
+ * viterbi_hip.h -- C ABI of the MI355X (gfx950) Viterbi decode backend.
+ *
+ * Drop-in boundary for the decoder path of williamyang98/ka9q_viterbi_comparison: the reference harness
+ * drives every third-party decoder through five free functions over an opaque handle
+ *      create / init / update_*_blk / chainback / delete
+ * (ka9q_libfec_port/viterbi27_sse2.h:3-8, viterbi29_sse2.h, viterbi615_sse2.h, viterbi224_sse2.h;
+ *  spiral/spiral47.h:5-9, spiral49.h) wrapped by src/ka9q_interface.h:12-55 / src/spiral_interface.h:13-56.
+ * This header declares the same five functions per code for the HIP backend (one frame per handle, host
+ * pointers, blocking -- exactly the reference contract), plus an additive batched / device-pointer API
+ * (`vhip_*`) that decodes thousands of independent frames per launch.
+ *
+ * Plain C: pointers and sizes only.  The library is ka9q_viterbi_comparison_amd/csrc/libviterbi_hip.so.
+ * Every function fails loudly (NULL / negative return, message in vhip_last_error()) when no gfx950 device
+ * or kernel image is available; there is no CPU fallback.
+ */
+#ifndef VITERBI_HIP_H
+#define VITERBI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Code identifiers (numbering shared with oracle/viterbi_oracle.h so tests can iterate both). */
+enum vhip_code {
+    VHIP_KA9Q27 = 0,   /* K=7  r=1/2, ka9q u8 modular arithmetic  (viterbi27_sse2.cpp)   */
+    VHIP_KA9Q29 = 1,   /* K=9  r=1/2, ka9q u8 modular arithmetic  (viterbi29_sse2.cpp)   */
+    VHIP_KA9Q615 = 2,  /* K=15 r=1/6, ka9q i16 saturating         (viterbi615_sse2.cpp)  */
+    VHIP_KA9Q224 = 3,  /* K=24 r=1/2, ka9q i16 saturating         (viterbi224_sse2.cpp)  */
+    VHIP_SPIRAL47 = 4, /* K=7  r=1/4, spiral u8 saturating        (spiral47.cpp)         */
+    VHIP_SPIRAL49 = 5, /* K=9  r=1/4, spiral u8 saturating        (spiral49.cpp)         */
+    VHIP_NUM_CODES = 6
+};
+
+typedef struct vhip_decoder vhip_decoder;
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched API (additive; SURVEY.md §8b "Batch extension").
+ *
+ * Semantics follow the reference per frame:
+ *  - poly: R ints, K-bit tap masks on sr=(state<<1)|bit; every polynomial must have bit K-1 and bit 0
+ *    set (butterfly symmetry, viterbi27_sse2.cpp:149-152); otherwise create returns NULL.
+ *  - len:  trellis steps per frame including the K-1 tail (src/main.cpp:247).
+ *  - update: `syms` holds nframes frames, frame-major, each nbits*R bytes step-major (src/util.h:31-48),
+ *    offset-binary u8 (0 = strong 0, 255 = strong 1).  ka9q codes are incremental (rows are appended at the
+ *    handle's decision pointer, viterbi27_sse2.cpp:121,174); spiral codes restart at row 0 on every call and
+ *    drop an odd last step (spiral47.cpp:536-538).
+ *  - chainback: writes ceil(nbits/8) bytes per frame, frame-major, MSB-first (viterbi27_sse2.cpp:98-103).
+ *    Return value: 0, or for VHIP_KA9Q615 with nframes==1 the end-state path metric
+ *    (viterbi615_sse2.cpp:76,90); negative on error.
+ * ------------------------------------------------------------------------------------------------ */
+vhip_decoder *vhip_create(int code, const int *poly, int len, int nframes);
+int vhip_init(vhip_decoder *p, int starting_state);
+/* host-pointer, blocking (copies H2D / D2H around the kernels) */
+int vhip_update(vhip_decoder *p, const unsigned char *syms, int nbits);
+int vhip_chainback(vhip_decoder *p, unsigned char *data, unsigned int nbits, unsigned int endstate);
+/* device-pointer, asynchronous on the handle's stream (inputs already resident in HBM) */
+int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits);
+int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbits, unsigned int endstate);
+void vhip_delete(vhip_decoder *p);
+
+/* Stream / device plumbing.  `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
+ * NULL selects the device's default stream. */
+int vhip_set_stream(vhip_decoder *p, void *stream);
+int vhip_sync(vhip_decoder *p);
+int vhip_device_count(void);
+const char *vhip_last_error(void);
+
+/* Kernel variant selection (0 = automatic).  Exposed so parity tests can pin every kernel family. */
+enum vhip_variant {
+    VHIP_VARIANT_AUTO = 0,
+    VHIP_VARIANT_LDS = 1,   /* one workgroup per frame, metrics ping-pong in LDS, natural decision rows */
+    VHIP_VARIANT_REGS = 2,  /* frames across lanes, packed metrics in VGPRs (K<=9) */
+    VHIP_VARIANT_HBM = 3    /* K=24: metrics tiled through HBM */
+};
+int vhip_set_variant(vhip_decoder *p, int variant);
+int vhip_get_variant(const vhip_decoder *p);
+
+/* Introspection for parity tests (blocking): natural decision bitmap rows (bit n of a row = new state n,
+ * 2^(K-1)/8 bytes per row) and current path metrics in natural units widened to int32. */
+int vhip_read_decision_rows(vhip_decoder *p, int frame, int row0, int nrows, unsigned char *out);
+int vhip_read_metrics(vhip_decoder *p, int frame, int32_t *out);
+int vhip_rows_written(const vhip_decoder *p);
+int vhip_code_K(int code);
+int vhip_code_R(int code);
+/* Bytes of HBM the handle holds (decision history + metrics + staging). */
+size_t vhip_device_bytes(const vhip_decoder *p);
+
+/* ------------------------------------------------------------------------------------------------
+ * Synthetic frames (analogue of src/util.h:8-62: random payload -> convolutional encoder -> soft symbols).
+ * Integer-only and counter-based so that host and device generators are bit-identical:
+ *   payload byte i of frame f  = splitmix64 stream keyed by (seed, f)
+ *   symbol = clamp(round(127.5 + amp*(2c-1) + noise), 0, 255), noise = Irwin-Hall(8) scaled by noise_q12
+ * amp_q16 = amplitude * 65536 (127.5*65536 with noise_q12 = 0 gives the reference's hard 0/255 symbols).
+ * ------------------------------------------------------------------------------------------------ */
+int vhip_noise_q12_from_ebn0(int R, double amp, double ebn0_db);
+int vhip_gen_frames_host(int K, int R, const int *poly, uint64_t seed, uint64_t frame0, int nframes,
+                         int payload_bytes, int amp_q16, int noise_q12, unsigned char *payload,
+                         unsigned char *syms);
+int vhip_gen_frames_dev(int K, int R, const int *poly, uint64_t seed, uint64_t frame0, int nframes,
+                        int payload_bytes, int amp_q16, int noise_q12, unsigned char *d_payload,
+                        unsigned char *d_syms, void *stream);
+/* Bit errors between two device byte buffers (BER reduction, src/util.h:64-73), blocking. */
+long long vhip_count_bit_errors_dev(const unsigned char *d_a, const unsigned char *d_b, size_t nbytes,
+                                    void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Reference-shaped entry points: one frame per handle, host pointers, blocking.
+ * Same signatures as the ka9q / spiral headers cited above with `_sse2` -> `_hip`.
+ * ------------------------------------------------------------------------------------------------ */
+#define VHIP_DECLARE_FIVE(T, CREATE, INIT, UPDATE, CHAINBACK, DELETE)                                   \
+    struct T;                                                                                           \
+    struct T *CREATE(const int *poly, int len);                                                         \
+    int INIT(struct T *p, int starting_state);                                                          \
+    void UPDATE(struct T *p, unsigned char *syms, int nbits);                                           \
+    int CHAINBACK(struct T *p, unsigned char *data, unsigned int nbits, unsigned int endstate);         \
+    void DELETE(struct T *p);
+
+/* replaces ka9q_libfec_port/viterbi27_sse2.h:3-8 */
+VHIP_DECLARE_FIVE(v27_hip, create_viterbi27_hip, init_viterbi27_hip, update_viterbi27_blk_hip,
+                  chainback_viterbi27_hip, delete_viterbi27_hip)
+/* replaces ka9q_libfec_port/viterbi29_sse2.h:3-8 */
+VHIP_DECLARE_FIVE(v29_hip, create_viterbi29_hip, init_viterbi29_hip, update_viterbi29_blk_hip,
+                  chainback_viterbi29_hip, delete_viterbi29_hip)
+/* replaces ka9q_libfec_port/viterbi615_sse2.h:3-8 */
+VHIP_DECLARE_FIVE(v615_hip, create_viterbi615_hip, init_viterbi615_hip, update_viterbi615_blk_hip,
+                  chainback_viterbi615_hip, delete_viterbi615_hip)
+/* replaces ka9q_libfec_port/viterbi224_sse2.h:3-8 */
+VHIP_DECLARE_FIVE(v224_hip, create_viterbi224_hip, init_viterbi224_hip, update_viterbi224_blk_hip,
+                  chainback_viterbi224_hip, delete_viterbi224_hip)
+/* replaces spiral/spiral47.h:5-9 */
+VHIP_DECLARE_FIVE(spiral47_hip, create_spiral47_hip, init_spiral47_hip, update_spiral47_hip,
+                  chainback_spiral47_hip, delete_spiral47_hip)
+/* replaces spiral/spiral49.h:5-9 */
+VHIP_DECLARE_FIVE(spiral49_hip, create_spiral49_hip, init_spiral49_hip, update_spiral49_hip,
+                  chainback_spiral49_hip, delete_spiral49_hip)
+
+#ifdef __cplusplus
+}
+#endif
+#endif

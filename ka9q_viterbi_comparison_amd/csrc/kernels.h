@@ -1,0 +1,54 @@
+// kernels.h -- launch interfaces between the C-ABI layer (viterbi_hip_api.hip) and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace vh {
+
+// ---------------------------------------------------------------- acs_lds.hip (K <= 15, any polynomial)
+struct AcsLdsArgs {
+    const unsigned char *syms;  // [nframes][sym_stride] offset-binary u8, step-major
+    size_t sym_stride;          // bytes between frames
+    int nsteps;                 // trellis steps to run
+    int row0;                   // first decision row to write
+    int cap_rows;               // rows allocated per frame
+    int nframes;
+    unsigned char *dec;         // natural rows: [nframes][cap_rows][N/8]
+    int16_t *metrics;           // [nframes][N] persistent path metrics (natural units)
+    int poly[8];
+};
+hipError_t launch_acs_lds(int code, const AcsLdsArgs &a, hipStream_t stream);
+hipError_t launch_init_metrics(int16_t *metrics, size_t n_per_frame, int nframes, int init_all, int init_start,
+                               unsigned start_state, hipStream_t stream);
+
+// ---------------------------------------------------------------- chainback.hip (natural rows)
+struct ChainbackRowsArgs {
+    const unsigned char *dec;  // natural rows [nframes][cap_rows][N/8]
+    int cap_rows;
+    int rows_written;          // rows beyond this read as zero
+    int nframes;
+    unsigned char *data;       // [nframes][data_stride]
+    size_t data_stride;
+    unsigned nbits;
+    unsigned endstate;
+    int K;
+    int k224;                  // chainback_viterbi224_sse2 semantics (no tail skip, emits state&1)
+};
+hipError_t launch_chainback_rows(const ChainbackRowsArgs &a, hipStream_t stream);
+
+// ---------------------------------------------------------------- acs_k24.hip (K = 24, metrics in HBM)
+enum { K24F_PENDING = 0, K24F_MIN = 1, K24F_COUNT = 4 };  // device flag words
+hipError_t launch_k24_step(const int16_t *oldm, int16_t *newm, unsigned char *row, const unsigned char *d_syms, int step,
+                           const int *poly, int *flags, hipStream_t stream);
+hipError_t launch_k24_renorm(int16_t *m, int *flags, hipStream_t stream);  // min-reduce, subtract, clear flags
+hipError_t launch_k24_flags_reset(int *flags, hipStream_t stream);
+
+// ---------------------------------------------------------------- framegen.hip
+hipError_t launch_gen_frames(int K, int R, const int *poly, uint64_t seed, uint64_t frame0, int nframes,
+                             int payload_bytes, int amp_q16, int noise_q12, unsigned char *d_payload,
+                             unsigned char *d_syms, hipStream_t stream);
+hipError_t launch_count_bit_errors(const unsigned char *a, const unsigned char *b, size_t nbytes,
+                                   unsigned long long *d_count, hipStream_t stream);
+
+}  // namespace vh

@@ -1,0 +1,436 @@
+// viterbi_hip_api.hip -- C-ABI layer of the MI355X Viterbi backend (include/viterbi_hip.h).
+//
+// Host-side mirror of the reference decoder interface: create / init / update_blk / chainback / delete over
+// an opaque handle (ka9q_libfec_port/viterbi27_sse2.h:3-8; adapter src/ka9q_interface.h:28-55), generalised
+// to `nframes` independent frames per handle.  The handle owns the device buffers (decision history, path
+// metrics, staging) and a stream; kernels live in acs_lds.hip / acs_regs.hip / acs_k24.hip / chainback.hip.
+// There is no CPU decode path here: without a gfx950 device every entry point fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/viterbi_hip.h"
+#include "framegen.h"
+#include "kernels.h"
+#include "viterbi_codes.h"
+
+namespace vh {
+void gen_frames_host(int K, int R, const int *poly, uint64_t seed, uint64_t frame0, int nframes, int payload_bytes,
+                     int amp_q16, int noise_q12, unsigned char *payload, unsigned char *syms);
+}
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(const char *what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof(buf), "viterbi_hip: %s: %s", what, hipGetErrorString(e));
+    else
+        snprintf(buf, sizeof(buf), "viterbi_hip: %s", what);
+    g_last_error = buf;
+    if (getenv("VHIP_VERBOSE")) fprintf(stderr, "%s\n", buf);
+    return -1;
+}
+
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t _e = (expr);                        \
+        if (_e != hipSuccess) return fail(#expr, _e);  \
+    } while (0)
+
+}  // namespace
+
+struct vhip_decoder {
+    int code = 0, K = 0, R = 0;
+    unsigned N = 0;
+    int poly[8] = {0};
+    int len = 0, cap_rows = 0, nframes = 0;
+    int incremental = 1;
+    int variant = VHIP_VARIANT_LDS;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    size_t row_bytes = 0;
+    unsigned char *d_dec = nullptr;  // natural rows [nframes][cap_rows][N/8]
+    int16_t *d_metrics = nullptr;    // [nframes][N]; K=24: [nframes][2][N] ping-pong
+    int *d_flags = nullptr;
+    unsigned char *d_syms_stage = nullptr;
+    size_t syms_stage_bytes = 0;
+    unsigned char *d_data_stage = nullptr;
+    size_t data_stage_bytes = 0;
+    int pos = 0;
+    std::vector<int> k24_cur;  // per frame: which half of the ping-pong holds the current metrics
+    size_t total_bytes = 0;
+};
+
+namespace {
+
+int init_all_of(int code) {
+    switch (code) {
+    case VHIP_KA9Q27: return vh::Code27::init_all;
+    case VHIP_KA9Q29: return vh::Code29::init_all;
+    case VHIP_KA9Q615: return vh::Code615::init_all;
+    case VHIP_KA9Q224: return vh::Code224::init_all;
+    case VHIP_SPIRAL47: return vh::Code47::init_all;
+    case VHIP_SPIRAL49: return vh::Code49::init_all;
+    }
+    return 0;
+}
+int init_start_of(int code) {
+    switch (code) {
+    case VHIP_KA9Q615: return vh::Code615::init_start;
+    case VHIP_KA9Q224: return vh::Code224::init_start;
+    }
+    return 0;
+}
+
+int ensure_stage(unsigned char **buf, size_t *cap, size_t need, size_t *total) {
+    if (*cap >= need) return 0;
+    if (*buf) {
+        (void)hipFree(*buf);
+        *total -= *cap;
+        *buf = nullptr;
+        *cap = 0;
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(buf), need));
+    *cap = need;
+    *total += need;
+    return 0;
+}
+
+// K=24: run `steps` trellis steps of frame f speculatively, replaying after each renormalisation event.
+int k24_update_frame(vhip_decoder *p, int f, const unsigned char *d_syms, int steps, int row0) {
+    const size_t NN = p->N;
+    int16_t *buf[2] = {p->d_metrics + (size_t)f * 2 * NN, p->d_metrics + (size_t)f * 2 * NN + NN};
+    unsigned char *rows = p->d_dec + (size_t)f * p->cap_rows * p->row_bytes;
+    int cur = p->k24_cur[f];
+    constexpr int BATCH = 128;
+    int t = 0;
+    while (t < steps) {
+        const int end = std::min(steps, t + BATCH);
+        for (int i = t; i < end; i++) {
+            const int o = cur ^ ((i - t) & 1);
+            HIP_TRY(vh::launch_k24_step(buf[o], buf[o ^ 1], rows + (size_t)(row0 + i) * p->row_bytes, d_syms, i, p->poly,
+                                        p->d_flags, p->stream));
+        }
+        int pending = 0;
+        HIP_TRY(hipMemcpyAsync(&pending, p->d_flags + vh::K24F_PENDING, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        if (pending == 0) {
+            cur ^= (end - t) & 1;
+            t = end;
+        } else {
+            const int r = pending - 1;  // steps t..r ran; r+1.. returned early
+            if (r < t || r >= end) return fail("K=24 renormalisation flag out of range");
+            cur ^= (r - t + 1) & 1;
+            HIP_TRY(vh::launch_k24_renorm(buf[cur], p->d_flags, p->stream));
+            t = r + 1;
+        }
+    }
+    p->k24_cur[f] = cur;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *vhip_last_error(void) { return g_last_error.c_str(); }
+
+int vhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int vhip_code_K(int code) { return vh::code_info(code).K; }
+int vhip_code_R(int code) { return vh::code_info(code).R; }
+
+vhip_decoder *vhip_create(int code, const int *poly, int len, int nframes) {
+    const vh::CodeInfo ci = vh::code_info(code);
+    if (ci.K == 0) {
+        fail("create: unknown code");
+        return nullptr;
+    }
+    if (!poly || len < 0 || nframes < 1) {
+        fail("create: bad arguments");
+        return nullptr;
+    }
+    for (int r = 0; r < ci.R; r++) {
+        // butterfly symmetry needs taps on the newest and the oldest register bit (viterbi27_sse2.cpp:149-152)
+        if (poly[r] <= 0 || !(poly[r] & 1) || !((poly[r] >> (ci.K - 1)) & 1) || (poly[r] >> ci.K)) {
+            fail("create: every polynomial must be a positive K-bit mask with bit 0 and bit K-1 set");
+            return nullptr;
+        }
+    }
+    if (vhip_device_count() < 1) {
+        fail("create: no HIP device visible (this backend has no CPU fallback)");
+        return nullptr;
+    }
+    vhip_decoder *p = new vhip_decoder();
+    p->code = code;
+    p->K = ci.K;
+    p->R = ci.R;
+    p->N = 1u << (ci.K - 1);
+    for (int r = 0; r < ci.R; r++) p->poly[r] = poly[r];
+    p->len = len;
+    p->nframes = nframes;
+    p->incremental = ci.incremental;
+    // rows: ka9q27/29/615 and spiral allocate len+K-1 (viterbi27_sse2.cpp:72, spiral47.cpp:79), ka9q224 len (:61)
+    p->cap_rows = (code == VHIP_KA9Q224) ? len : len + ci.K - 1;
+    p->row_bytes = p->N / 8;
+    p->variant = (code == VHIP_KA9Q224) ? VHIP_VARIANT_HBM : VHIP_VARIANT_LDS;
+    (void)hipGetDevice(&p->device);
+    const size_t dec_bytes = (size_t)nframes * (size_t)p->cap_rows * p->row_bytes;
+    const size_t met_bytes = (size_t)nframes * p->N * sizeof(int16_t) * (code == VHIP_KA9Q224 ? 2 : 1);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&p->d_dec), dec_bytes ? dec_bytes : 16);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_metrics), met_bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_flags), sizeof(int) * 16);
+    if (e == hipSuccess) e = hipMemset(p->d_dec, 0, dec_bytes ? dec_bytes : 16);
+    if (e == hipSuccess) e = hipMemset(p->d_flags, 0, sizeof(int) * 16);
+    if (e != hipSuccess) {
+        fail("create: device allocation", e);
+        vhip_delete(p);
+        return nullptr;
+    }
+    p->total_bytes = dec_bytes + met_bytes + 64;
+    p->k24_cur.assign(nframes, 0);
+    if (vhip_init(p, 0) != 0) {
+        vhip_delete(p);
+        return nullptr;
+    }
+    if (hipStreamSynchronize(p->stream) != hipSuccess) {
+        fail("create: init failed");
+        vhip_delete(p);
+        return nullptr;
+    }
+    return p;
+}
+
+void vhip_delete(vhip_decoder *p) {
+    if (!p) return;  // delete(NULL) is a no-op in the reference too (viterbi27_sse2.cpp:108-115)
+    if (p->d_dec) (void)hipFree(p->d_dec);
+    if (p->d_metrics) (void)hipFree(p->d_metrics);
+    if (p->d_flags) (void)hipFree(p->d_flags);
+    if (p->d_syms_stage) (void)hipFree(p->d_syms_stage);
+    if (p->d_data_stage) (void)hipFree(p->d_data_stage);
+    delete p;
+}
+
+int vhip_set_stream(vhip_decoder *p, void *stream) {
+    if (!p) return fail("set_stream: NULL handle");
+    p->stream = reinterpret_cast<hipStream_t>(stream);
+    return 0;
+}
+
+int vhip_sync(vhip_decoder *p) {
+    if (!p) return fail("sync: NULL handle");
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return 0;
+}
+
+int vhip_set_variant(vhip_decoder *p, int variant) {
+    if (!p) return fail("set_variant: NULL handle");
+    if (p->pos != 0) return fail("set_variant: only before the first update after init");
+    if (variant == VHIP_VARIANT_AUTO) variant = (p->code == VHIP_KA9Q224) ? VHIP_VARIANT_HBM : VHIP_VARIANT_LDS;
+    if (p->code == VHIP_KA9Q224 && variant != VHIP_VARIANT_HBM) return fail("set_variant: K=24 supports only HBM");
+    if (p->code != VHIP_KA9Q224 && variant != VHIP_VARIANT_LDS) return fail("set_variant: unsupported for this code");
+    p->variant = variant;
+    return 0;
+}
+int vhip_get_variant(const vhip_decoder *p) { return p ? p->variant : -1; }
+int vhip_rows_written(const vhip_decoder *p) { return p ? p->pos : -1; }
+size_t vhip_device_bytes(const vhip_decoder *p) { return p ? p->total_bytes : 0; }
+
+// init_viterbi27_sse2 (viterbi27_sse2.cpp:42-54) for every frame of the handle
+int vhip_init(vhip_decoder *p, int starting_state) {
+    if (!p) return fail("init: NULL handle");  // viterbi224_sse2.cpp:36-37 returns -1 on NULL
+    const unsigned start = (unsigned)starting_state & (p->N - 1);
+    const int ia = init_all_of(p->code), is = init_start_of(p->code);
+    if (p->code == VHIP_KA9Q224) {
+        // only the first half of each frame's ping-pong needs filling; mark it current
+        for (int f = 0; f < p->nframes; f++) {
+            HIP_TRY(vh::launch_init_metrics(p->d_metrics + (size_t)f * 2 * p->N, p->N, 1, ia, is, start, p->stream));
+            p->k24_cur[f] = 0;
+        }
+        HIP_TRY(vh::launch_k24_flags_reset(p->d_flags, p->stream));
+    } else {
+        HIP_TRY(vh::launch_init_metrics(p->d_metrics, p->N, p->nframes, ia, is, start, p->stream));
+    }
+    p->pos = 0;
+    return 0;
+}
+
+int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
+    if (!p) return fail("update: NULL handle");
+    if (nbits <= 0) return 0;
+    int steps = nbits, row0 = p->pos;
+    if (!p->incremental) {  // spiral47.cpp:536-538: restart at row 0, nbits/2 double steps
+        row0 = 0;
+        steps = (nbits / 2) * 2;
+    }
+    if (row0 + steps > p->cap_rows) return fail("update: more trellis steps than the handle was created for");
+    const size_t sym_stride = (size_t)nbits * p->R;
+    if (p->code == VHIP_KA9Q224) {
+        for (int f = 0; f < p->nframes; f++)
+            if (k24_update_frame(p, f, d_syms + (size_t)f * sym_stride, steps, row0) != 0) return -1;
+    } else {
+        vh::AcsLdsArgs a;
+        a.syms = d_syms;
+        a.sym_stride = sym_stride;
+        a.nsteps = steps;
+        a.row0 = row0;
+        a.cap_rows = p->cap_rows;
+        a.nframes = p->nframes;
+        a.dec = p->d_dec;
+        a.metrics = p->d_metrics;
+        for (int r = 0; r < 8; r++) a.poly[r] = p->poly[r];
+        HIP_TRY(vh::launch_acs_lds(p->code, a, p->stream));
+    }
+    p->pos = row0 + steps;
+    return 0;
+}
+
+int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbits, unsigned int endstate) {
+    if (!p) return fail("chainback: NULL handle");
+    if (nbits == 0) return 0;
+    vh::ChainbackRowsArgs a;
+    a.dec = p->d_dec;
+    a.cap_rows = p->cap_rows;
+    a.rows_written = p->pos;
+    a.nframes = p->nframes;
+    a.data = d_data;
+    a.data_stride = (nbits + 7) / 8;
+    a.nbits = nbits;
+    a.endstate = endstate;
+    a.K = p->K;
+    a.k224 = (p->code == VHIP_KA9Q224);
+    HIP_TRY(vh::launch_chainback_rows(a, p->stream));
+    return 0;
+}
+
+int vhip_update(vhip_decoder *p, const unsigned char *syms, int nbits) {
+    if (!p) return fail("update: NULL handle");
+    if (nbits <= 0) return 0;
+    const size_t bytes = (size_t)p->nframes * (size_t)nbits * p->R;
+    if (ensure_stage(&p->d_syms_stage, &p->syms_stage_bytes, bytes, &p->total_bytes) != 0) return -1;
+    HIP_TRY(hipMemcpyAsync(p->d_syms_stage, syms, bytes, hipMemcpyHostToDevice, p->stream));
+    if (vhip_update_dev(p, p->d_syms_stage, nbits) != 0) return -1;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return 0;
+}
+
+int vhip_chainback(vhip_decoder *p, unsigned char *data, unsigned int nbits, unsigned int endstate) {
+    if (!p) return fail("chainback: NULL handle");
+    int ret = 0;
+    if (p->code == VHIP_KA9Q615 && p->nframes == 1) {
+        // chainback_viterbi615_sse2 returns old_metrics->s[endstate]            viterbi615_sse2.cpp:76,90
+        int16_t m = 0;
+        HIP_TRY(hipMemcpyAsync(&m, p->d_metrics + (endstate % p->N), sizeof(m), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        ret = m;
+    }
+    if (nbits == 0) return ret;
+    const size_t stride = (nbits + 7) / 8;
+    const size_t bytes = (size_t)p->nframes * stride;
+    if (ensure_stage(&p->d_data_stage, &p->data_stage_bytes, bytes, &p->total_bytes) != 0) return -1;
+    if (vhip_chainback_dev(p, p->d_data_stage, nbits, endstate) != 0) return -1;
+    HIP_TRY(hipMemcpyAsync(data, p->d_data_stage, bytes, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return ret;
+}
+
+int vhip_read_decision_rows(vhip_decoder *p, int frame, int row0, int nrows, unsigned char *out) {
+    if (!p) return fail("read_decision_rows: NULL handle");
+    if (frame < 0 || frame >= p->nframes || row0 < 0 || nrows < 0 || row0 + nrows > p->cap_rows)
+        return fail("read_decision_rows: out of range");
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(out, p->d_dec + ((size_t)frame * p->cap_rows + row0) * p->row_bytes, (size_t)nrows * p->row_bytes,
+                      hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int vhip_read_metrics(vhip_decoder *p, int frame, int32_t *out) {
+    if (!p) return fail("read_metrics: NULL handle");
+    if (frame < 0 || frame >= p->nframes) return fail("read_metrics: out of range");
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    std::vector<int16_t> tmp(p->N);
+    const int16_t *src = (p->code == VHIP_KA9Q224)
+                             ? p->d_metrics + ((size_t)frame * 2 + p->k24_cur[frame]) * p->N
+                             : p->d_metrics + (size_t)frame * p->N;
+    HIP_TRY(hipMemcpy(tmp.data(), src, (size_t)p->N * sizeof(int16_t), hipMemcpyDeviceToHost));
+    for (unsigned i = 0; i < p->N; i++) out[i] = tmp[i];
+    return 0;
+}
+
+// ---------------------------------------------------------------- synthetic frames
+int vhip_noise_q12_from_ebn0(int R, double amp, double ebn0_db) {
+    // BPSK amplitude `amp` LSBs, code rate 1/R: Es/N0 = (Eb/N0)/R, sigma^2 = amp^2 / (2 Es/N0)
+    const double esn0 = std::pow(10.0, ebn0_db / 10.0) / (double)R;
+    const double sigma = amp / std::sqrt(2.0 * esn0);
+    return (int)std::llround(sigma * 65536.0 * 4096.0 / VH_FG_SIGMA_C2);
+}
+
+int vhip_gen_frames_host(int K, int R, const int *poly, uint64_t seed, uint64_t frame0, int nframes, int payload_bytes,
+                         int amp_q16, int noise_q12, unsigned char *payload, unsigned char *syms) {
+    if (K < 2 || K > 32 || R < 1 || R > 8 || !poly || nframes < 0 || payload_bytes < 0) return fail("gen_frames: bad arguments");
+    vh::gen_frames_host(K, R, poly, seed, frame0, nframes, payload_bytes, amp_q16, noise_q12, payload, syms);
+    return 0;
+}
+
+int vhip_gen_frames_dev(int K, int R, const int *poly, uint64_t seed, uint64_t frame0, int nframes, int payload_bytes,
+                        int amp_q16, int noise_q12, unsigned char *d_payload, unsigned char *d_syms, void *stream) {
+    if (K < 2 || K > 32 || R < 1 || R > 8 || !poly || nframes < 0 || payload_bytes < 0) return fail("gen_frames: bad arguments");
+    if (nframes == 0) return 0;
+    HIP_TRY(vh::launch_gen_frames(K, R, poly, seed, frame0, nframes, payload_bytes, amp_q16, noise_q12, d_payload, d_syms,
+                                  reinterpret_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+long long vhip_count_bit_errors_dev(const unsigned char *d_a, const unsigned char *d_b, size_t nbytes, void *stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    unsigned long long *d_count = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&d_count), sizeof(*d_count)) != hipSuccess) return fail("count_bit_errors: alloc");
+    unsigned long long h = 0;
+    hipError_t e = hipMemsetAsync(d_count, 0, sizeof(*d_count), s);
+    if (e == hipSuccess && nbytes) e = vh::launch_count_bit_errors(d_a, d_b, nbytes, d_count, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d_count, sizeof(h), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_count);
+    if (e != hipSuccess) return fail("count_bit_errors", e);
+    return (long long)h;
+}
+
+// ---------------------------------------------------------------- reference-shaped five functions per code
+#define VHIP_DEFINE_FIVE(T, CODE, CREATE, INIT, UPDATE, CHAINBACK, DELETE)                                            \
+    struct T *CREATE(const int *poly, int len) { return reinterpret_cast<struct T *>(vhip_create(CODE, poly, len, 1)); } \
+    int INIT(struct T *p, int starting_state) { return vhip_init(reinterpret_cast<vhip_decoder *>(p), starting_state); } \
+    void UPDATE(struct T *p, unsigned char *syms, int nbits) {                                                        \
+        if (vhip_update(reinterpret_cast<vhip_decoder *>(p), syms, nbits) != 0)                                       \
+            fprintf(stderr, "%s\n", vhip_last_error()); /* void in the reference ABI: report loudly */                \
+    }                                                                                                                 \
+    int CHAINBACK(struct T *p, unsigned char *data, unsigned int nbits, unsigned int endstate) {                      \
+        return vhip_chainback(reinterpret_cast<vhip_decoder *>(p), data, nbits, endstate);                            \
+    }                                                                                                                 \
+    void DELETE(struct T *p) { vhip_delete(reinterpret_cast<vhip_decoder *>(p)); }
+
+VHIP_DEFINE_FIVE(v27_hip, VHIP_KA9Q27, create_viterbi27_hip, init_viterbi27_hip, update_viterbi27_blk_hip,
+                 chainback_viterbi27_hip, delete_viterbi27_hip)
+VHIP_DEFINE_FIVE(v29_hip, VHIP_KA9Q29, create_viterbi29_hip, init_viterbi29_hip, update_viterbi29_blk_hip,
+                 chainback_viterbi29_hip, delete_viterbi29_hip)
+VHIP_DEFINE_FIVE(v615_hip, VHIP_KA9Q615, create_viterbi615_hip, init_viterbi615_hip, update_viterbi615_blk_hip,
+                 chainback_viterbi615_hip, delete_viterbi615_hip)
+VHIP_DEFINE_FIVE(v224_hip, VHIP_KA9Q224, create_viterbi224_hip, init_viterbi224_hip, update_viterbi224_blk_hip,
+                 chainback_viterbi224_hip, delete_viterbi224_hip)
+VHIP_DEFINE_FIVE(spiral47_hip, VHIP_SPIRAL47, create_spiral47_hip, init_spiral47_hip, update_spiral47_hip,
+                 chainback_spiral47_hip, delete_spiral47_hip)
+VHIP_DEFINE_FIVE(spiral49_hip, VHIP_SPIRAL49, create_spiral49_hip, init_spiral49_hip, update_spiral49_hip,
+                 chainback_spiral49_hip, delete_spiral49_hip)
+
+}  // extern "C"
