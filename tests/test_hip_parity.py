@@ -1,0 +1,185 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Bar: bit-exact decision rows, path metrics, decoded bytes and return codes (integer work).
+"""
+import numpy as np
+import pytest
+
+from common import GPU_CODES, bit_errors, frames, spec_of
+from ka9q_viterbi_comparison_amd import HipViterbi, codes as C
+from ka9q_viterbi_comparison_amd import VARIANT_AUTO, VARIANT_LDS, VARIANT_REGS
+from oracle_lib import OracleDecoder
+
+pytestmark = pytest.mark.gpu
+HAVE_REGS = False  # flipped on when acs_regs.hip lands
+
+
+def variants_for(code):
+    if code == C.KA9Q224:
+        return [VARIANT_AUTO]
+    if code == C.KA9Q615:
+        return [VARIANT_LDS]
+    return [VARIANT_LDS, VARIANT_REGS] if HAVE_REGS else [VARIANT_LDS]
+
+
+def oracle_decode(code, syms, steps, nbits, endstate=0, start=0, splits=None):
+    spec = spec_of(code)
+    o = OracleDecoder(code, spec.poly, steps)
+    o.init(start)
+    if splits is None:
+        o.update(syms, steps)
+    else:
+        off = 0
+        for n in splits:
+            o.update(syms[off * spec.R:], n)
+            off += n
+    data, rc = o.chainback(nbits, endstate)
+    out = dict(rows=o.rows(), metrics=o.metrics(), data=data, rc=rc, renorms=o.renorms)
+    o.close()
+    return out
+
+
+CASES = []
+for _code in GPU_CODES:
+    for _v in variants_for(_code):
+        CASES.append((_code, _v))
+
+
+@pytest.mark.parametrize("code,variant", CASES)
+@pytest.mark.parametrize("ebn0", ["hard", "awgn"])
+def test_batch_matches_oracle(code, variant, ebn0):
+    """A batch of frames: every decision row, final metric, decoded byte and return code equals the oracle's."""
+    spec = spec_of(code)
+    B = 8 if spec.K == 24 else (24 if spec.K == 15 else 40)
+    nframes = 1 if spec.K == 24 else (3 if spec.K == 15 else 70)  # 70: more than one wave of frames, ragged
+    steps = B * 8 + spec.K - 1
+    payload, syms = frames(code, 77 + code, nframes, B, None if ebn0 == "hard" else spec.ebn0_db)
+    dec = HipViterbi(spec.name, steps, nframes=nframes, variant=variant)
+    dec.reset()
+    dec.update(syms)
+    data, rc = dec.chainback(B * 8)
+    for f in range(nframes):
+        ref = oracle_decode(code, syms[f], steps, B * 8)
+        rows = dec.decision_rows(f, 0, ref["rows"].shape[0])
+        assert np.array_equal(rows, ref["rows"]), f"decision rows differ, frame {f}"
+        assert np.array_equal(dec.metrics(f), ref["metrics"]), f"metrics differ, frame {f}"
+        assert np.array_equal(data[f], ref["data"]), f"decoded bytes differ, frame {f}"
+        if code != C.KA9Q224:
+            assert bit_errors(data[f], payload[f]) == 0 or ebn0 == "awgn"
+    if nframes == 1:
+        assert rc == oracle_decode(code, syms[0], steps, B * 8)["rc"]
+    dec.close()
+
+
+@pytest.mark.parametrize("code,variant", [c for c in CASES if c[0] in (C.KA9Q27, C.KA9Q29, C.KA9Q615)])
+def test_incremental_update(code, variant):
+    """ka9q update is incremental (viterbi27_sse2.cpp:121,174): ragged splits give the same rows as one call."""
+    spec = spec_of(code)
+    B = 16
+    steps = B * 8 + spec.K - 1
+    nframes = 5 if spec.K < 15 else 2
+    _, syms = frames(code, 5, nframes, B, spec.ebn0_db)
+    splits = [1, 7, 30, 2, steps - 40]
+    dec = HipViterbi(spec.name, steps, nframes=nframes, variant=variant)
+    dec.reset()
+    off = 0
+    s3 = syms.reshape(nframes, steps, spec.R)
+    for n in splits:
+        dec.update(np.ascontiguousarray(s3[:, off:off + n, :]), nbits=n)
+        off += n
+    assert dec.rows_written == steps
+    data, _ = dec.chainback(B * 8)
+    for f in range(nframes):
+        ref = oracle_decode(code, syms[f], steps, B * 8)
+        assert np.array_equal(dec.decision_rows(f, 0, steps), ref["rows"])
+        assert np.array_equal(dec.metrics(f), ref["metrics"])
+        assert np.array_equal(data[f], ref["data"])
+    dec.close()
+
+
+@pytest.mark.parametrize("code,variant", [c for c in CASES if c[0] in (C.SPIRAL47, C.SPIRAL49)])
+def test_spiral_restart_and_odd_step(code, variant):
+    """spiral update restarts at row 0 on every call and drops an odd last step (spiral47.cpp:536-538)."""
+    spec = spec_of(code)
+    B = 8
+    steps = B * 8 + spec.K - 1  # even for K=7,9
+    _, syms = frames(code, 9, 4, B, spec.ebn0_db)
+    dec = HipViterbi(spec.name, steps, nframes=4, variant=variant)
+    dec.reset()
+    s3 = syms.reshape(4, steps, spec.R)
+    dec.update(np.ascontiguousarray(s3[:, :11, :]), nbits=11)  # runs 10 steps
+    assert dec.rows_written == 10
+    dec.update(syms, nbits=steps)  # restarts at row 0, metrics continue
+    for f in range(4):
+        o = OracleDecoder(code, spec.poly, steps)
+        o.update(s3[f, :11].reshape(-1), 11)
+        o.update(syms[f], steps)
+        assert np.array_equal(dec.decision_rows(f, 0, steps), o.rows(steps))
+        assert np.array_equal(dec.metrics(f), o.metrics())
+        o.close()
+    dec.close()
+
+
+@pytest.mark.parametrize("code,variant", CASES)
+def test_endstate_start_state_and_ragged_bits(code, variant):
+    """Non-zero starting state, non-zero end state, bit counts that are not multiples of 8."""
+    spec = spec_of(code)
+    if spec.K == 24:
+        pytest.skip("covered by test_k24_chainback_variants")
+    B = 12
+    steps = B * 8 + spec.K - 1
+    _, syms = frames(code, 21, 3, B, spec.ebn0_db)
+    N = 1 << (spec.K - 1)
+    for start, end, nbits in [(5, 0, B * 8), (N - 1, 3, B * 8 - 3), (0, N + 9, 13)]:
+        dec = HipViterbi(spec.name, steps, nframes=3, variant=variant)
+        dec.reset(start)
+        dec.update(syms)
+        data, _ = dec.chainback(nbits, endstate=end)
+        for f in range(3):
+            ref = oracle_decode(code, syms[f], steps, nbits, endstate=end, start=start)
+            assert np.array_equal(data[f], ref["data"])
+            assert np.array_equal(dec.metrics(f), ref["metrics"])
+        dec.close()
+
+
+def test_k24_chainback_variants():
+    """chainback_viterbi224_sse2 has no tail skip: pin both the harness call (nbits) and the
+    correct one (nbits+K-1)."""
+    code = C.KA9Q224
+    spec = spec_of(code)
+    B = 8
+    steps = B * 8 + spec.K - 1
+    payload, syms = frames(code, 3, 1, B, spec.ebn0_db)
+    dec = HipViterbi("224", steps)
+    dec.reset()
+    dec.update(syms)
+    o = OracleDecoder(code, spec.poly, steps)
+    o.update(syms[0], steps)
+    for nbits in (B * 8, steps, 13):
+        d, rc = dec.chainback(nbits)
+        r, rrc = o.chainback(nbits)
+        assert np.array_equal(d[0], r) and rc == rrc
+    d, _ = dec.chainback(steps)
+    assert bit_errors(d[0][:B], payload[0]) == 0
+    o.close()
+    dec.close()
+
+
+def test_k615_forced_renormalisation_and_return_value():
+    """Noisy K=15 frames renormalise several times (viterbi615_sse2.cpp:160-183) and chainback returns the end
+    state's path metric (:76,90)."""
+    code = C.KA9Q615
+    spec = spec_of(code)
+    B = 64
+    steps = B * 8 + spec.K - 1
+    _, syms = frames(code, 1234, 1, B, spec.ebn0_db)
+    ref = oracle_decode(code, syms[0], steps, B * 8)
+    assert ref["renorms"] >= 2
+    dec = HipViterbi("615", steps)
+    dec.reset()
+    dec.update(syms)
+    data, rc = dec.chainback(B * 8)
+    assert rc == ref["rc"]
+    assert np.array_equal(data[0], ref["data"])
+    assert np.array_equal(dec.metrics(0), ref["metrics"])
+    dec.close()
