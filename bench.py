@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the Viterbi decode hot path on MI355X.
+
+One "step" = one full decode pass of the hot path over one batch of synthetic frames already resident in
+HBM: init (reset metrics) + ACS update + chainback, exactly the three calls the reference times per sample
+(src/main.cpp:264-278).  Default workload = BASELINE.json configs[1]: K=7 r=1/2 (viterbi27), 65 536 frames x
+2048 info bits per GPU, AWGN soft symbols.  Frames are sharded across ranks (no data-path collective;
+torch.distributed is used only for the barrier and the max-over-ranks timing) -> "scaling": "weak".
+
+metric / value: coded symbols (incl. tail, the reference's definition scripts/tabulate_data.py:33) decoded per
+second over the whole job, Msymbols/s.  The JSON line also carries the ACS-update-only and chainback-only
+rates from HIP events, the HBM roofline of the dominant (ACS) kernel, and a CPU baseline timed on this host.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import concurrent.futures as cf
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from ka9q_viterbi_comparison_amd import HipViterbi, codes as C, count_bit_errors_dev, gen_frames_dev, noise_q12  # noqa: E402
+from ka9q_viterbi_comparison_amd.decoder import gen_frames_host  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes_per_frame_step(spec):
+    """R symbol bytes read + 2^(K-1)/8 decision bytes written per frame-step (metrics on chip);
+    K=24: 2*16 MiB metric read+write + 1 MiB row + 2."""
+    if spec.K == 24:
+        return 2 * (1 << 23) * 2 + (1 << 23) // 8 + 2
+    return spec.R + (1 << (spec.K - 1)) // 8
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(spec, payload_bits, budget_s=12.0):
+    """Times the CPU decoder on this host on a bounded sample of the same workload: the genuine reference objects
+    (oracle/_ref/libref.so, built from /root/reference in the build container) when present -> kind "reference";
+    else the plain-C restatement -> kind "port".  One frame per call, reset+update+chainback per frame
+    (src/main.cpp:257-280), first on 1 thread, then on all host cores (ctypes releases the GIL)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+
+    use_ref = ol.have_ref()
+    payload_bytes = payload_bits // 8
+    steps = payload_bits + spec.K - 1
+    nsample = 256
+    nq = noise_q12(spec.R, C.SOFT_AMP, spec.ebn0_db)
+    _, syms = gen_frames_host(spec, 0xC0FFEE, 0, nsample, payload_bytes, C.SOFT_AMP_Q16, nq)
+    w32 = spec.code == C.KA9Q615
+
+    def make():
+        return ol.RefDecoder(spec.code, spec.poly, steps, w32=w32) if use_ref else ol.OracleDecoder(spec.code, spec.poly, steps)
+
+    def work(dec, seconds):
+        lib, h, code = dec.lib, dec.h, spec.code
+        out = np.zeros(payload_bytes, dtype=np.uint8)
+        outp = out.ctypes.data_as(ctypes.c_void_p)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            s = syms[n % nsample]
+            sp = s.ctypes.data_as(ctypes.c_void_p)
+            if use_ref:
+                lib.ref_init(code, h, 0)
+                lib.ref_update(code, h, sp, steps)
+                lib.ref_chainback(code, h, outp, payload_bits, 0)
+            else:
+                lib.vo_init(h, 0)
+                lib.vo_update_blk(h, sp, steps)
+                lib.vo_chainback(h, outp, payload_bits, 0)
+            n += 1
+            if (n & 15) == 0 and time.perf_counter() - t0 >= seconds:
+                break
+        return n, time.perf_counter() - t0
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    decs = [make() for _ in range(cores)]  # created serially: the reference's table init is not thread-safe
+    n1, t1 = work(decs[0], budget_s * 0.4)
+    single = n1 * steps * spec.R / t1 / 1e6
+    with cf.ThreadPoolExecutor(cores) as ex:
+        t0 = time.perf_counter()
+        res = list(ex.map(lambda d: work(d, budget_s * 0.6), decs))
+        wall = time.perf_counter() - t0
+    nall = sum(r[0] for r in res)
+    multi = nall * steps * spec.R / wall / 1e6
+    for d in decs:
+        d.close()
+    return {
+        "value": round(multi, 3),
+        "unit": "Msymbols/s",
+        "cores": cores,
+        "kind": "reference" if use_ref else "port",
+        "single_thread_value": round(single, 3),
+        "sample": f"{n1}+{nall} one-frame decodes (reset+update+chainback) of K={spec.K} r=1/{spec.R} x {payload_bits} bits, "
+                  f"AWGN Eb/N0={spec.ebn0_db} dB, {budget_s:.0f} s budget; value = all {cores} threads, "
+                  f"single_thread_value = 1 thread",
+    }
+
+
+# ------------------------------------------------------------------------------------------------ main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--code", default="27", choices=sorted(C.CODES))
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU (default: BASELINE config for the code)")
+    ap.add_argument("--payload-bits", type=int, default=None)
+    ap.add_argument("--ebn0", type=float, default=None, help="Eb/N0 in dB; 'hard' symbols if --hard")
+    ap.add_argument("--hard", action="store_true", help="reference-style noise-free 0/255 symbols")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the decode path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+    if args.gpus != world and rank == 0:
+        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    spec = C.CODES[args.code]
+    defaults = {"27": (65536, 2048), "47": (65536, 2048), "29": (32768, 2048), "49": (32768, 2048),
+                "615": (4096, 2048), "224": (1, 2048)}
+    frames = args.frames or defaults[args.code][0]
+    payload_bits = args.payload_bits or defaults[args.code][1]
+    payload_bytes = payload_bits // 8
+    nsteps = payload_bits + spec.K - 1
+    ebn0 = spec.ebn0_db if args.ebn0 is None else args.ebn0
+
+    stream = torch.cuda.current_stream()
+    dev = torch.device("cuda", local_rank)
+    d_payload = torch.empty(frames * payload_bytes, dtype=torch.uint8, device=dev)
+    d_syms = torch.empty(frames * nsteps * spec.R, dtype=torch.uint8, device=dev)
+    d_out = torch.zeros(frames * payload_bytes, dtype=torch.uint8, device=dev)
+    if args.hard:
+        amp_q16, nq = C.HARD_AMP_Q16, 0
+    else:
+        amp_q16, nq = C.SOFT_AMP_Q16, noise_q12(spec.R, C.SOFT_AMP, ebn0)
+    # synthetic frames generated on the device, distinct per rank (frame ids rank*frames ...)
+    gen_frames_dev(spec, 0x5EED, rank * frames, frames, payload_bytes, amp_q16, nq, d_payload, d_syms, stream.cuda_stream)
+    dec = HipViterbi(args.code, nsteps, nframes=frames, variant=args.variant, stream=stream.cuda_stream)
+    # K=24's own chainback call convention needs nbits+K-1 to decode correctly; the harness call
+    # (nbits = payload bits) is what is timed, as in the reference.
+    cb_bits = payload_bits
+
+    def one_pass(ev=None):
+        dec.reset()
+        if ev:
+            ev[0].record(stream)
+        dec.update(d_syms, nbits=nsteps)
+        if ev:
+            ev[1].record(stream)
+        dec.chainback(cb_bits, out=d_out)
+        if ev:
+            ev[2].record(stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_pass()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_pass(events[i])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    upd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+    cb_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+    # correctness guard outside the timed region: decoded bytes vs transmitted payload (BER over the batch)
+    nerr = count_bit_errors_dev(d_out, d_payload, frames * payload_bytes, stream.cuda_stream) if spec.K != 24 else -1
+
+    if rank == 0:
+        total_syms = frames * nsteps * spec.R * n_gpus
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_syms * args.steps / elapsed / 1e6
+        abytes = algorithmic_bytes_per_frame_step(spec) * frames * nsteps  # per launch (one rank)
+        achieved = abytes / (upd_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.code}.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": f"Msymbols/s decoded, K={spec.K} r=1/{spec.R} (init + ACS update + chainback)",
+            "value": round(value, 3),
+            "unit": "Msymbols/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8" if spec.family != "ka9q-i16-sat" else "i16",
+            "data": "synthetic" + (" hard 0/255 symbols" if args.hard else f" AWGN Eb/N0={ebn0} dB, amplitude {C.SOFT_AMP}") + ", generated on device",
+            "config": {"workload": f"viterbi{spec.name}: K={spec.K} r=1/{spec.R}, {frames} frames/GPU x {payload_bits} info bits "
+                                   f"({nsteps} trellis steps, {nsteps * spec.R} symbols/frame)",
+                       "frames_per_gpu": frames, "payload_bits": payload_bits, "variant": dec.variant,
+                       "parallelism": f"frame-shard x{n_gpus}, no collective"},
+            "update_msym_s": round(frames * nsteps * spec.R * n_gpus / (upd_ms * 1e-3) / 1e6, 3),
+            "chainback_mbit_s": round(frames * cb_bits * n_gpus / (cb_ms * 1e-3) / 1e6, 3),
+            "update_ms": round(upd_ms, 4),
+            "chainback_ms": round(cb_ms, 4),
+            "bit_errors": int(nerr),
+            "payload_bits_total": frames * payload_bits,
+            "roofline": {"bound": "hbm", "kernel": "acs_update", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": abytes},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(spec, payload_bits, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    dec.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
