@@ -1,0 +1,490 @@
+// acs_regs.hip -- production ACS update kernel for K <= 9: frames across lanes, path metrics packed in VGPRs.
+//
+// Replaces update_viterbi27_blk_sse2 / update_viterbi29_blk_sse2 (ka9q_libfec_port/viterbi27_sse2.cpp:119-175,
+// viterbi29_sse2.cpp:108-164) and update_spiral47 / update_spiral49 (spiral/spiral47.cpp:131-538,
+// spiral49.cpp:132-1540) for the polynomials the harness uses (src/main.cpp:367,377,386,396).
+//
+// Design (MI355X-first, not a translation of the SSE2 butterflies):
+//  * L = 2^LB adjacent lanes own one frame (L = 1, 2 or 4, picked so the batch fills >= 2 waves per SIMD);
+//    a wave therefore advances 64/L independent frames per instruction and there is no LDS, no barrier.
+//  * The N = 2^(K-1) metrics of a frame are 16-bit fields packed two per VGPR (v_pk_* integer ops):
+//    N/(2L) registers per lane.  u8-modular metrics (ka9q) sit in the HIGH byte of each field so that the
+//    16-bit wrap of v_pk_add_u16 IS the mod-256 wrap of _mm_add_epi8 and the sign of a 16-bit difference IS
+//    the sign of the 8-bit one; u8-saturating metrics (spiral) are (m<<8)|0xff so that the 16-bit clamp of
+//    v_pk_add_u16 ... clamp IS _mm_adds_epu8.
+//  * In-place trellis with a rotating index map: new[2j] is written where old[j] lived and new[2j+1] where
+//    old[j+H] lived, so position p holds state rotl^t(p) before step t.  No metric ever moves between
+//    registers; the butterfly partner of step t differs in position bit (K-2 - t mod (K-1)), which is a
+//    register-index bit (pure in-lane), the half bit (one v_perm), or a lane bit (one DPP quad_perm move).
+//    The K-1 phases are fully unrolled, so every register index and every branch-table class is a
+//    compile-time constant; the branch metric of a butterfly is a static pick from 2^R per-step values.
+//  * Decisions: min(positive-part, 1<<k) turns a packed ACS by-product into bit k / bit 16+k, OR-ed into
+//    accumulators; one 32-bit word per 16 registers leaves per step, laid out [group][row][word][lane] so a
+//    wave store is 256 contiguous bytes.  chainback_regs_kernel below walks exactly this layout.
+//
+// Algorithmic HBM bytes per frame-step are those of the reference layout: R symbol bytes in, N/8 decision
+// bytes out; the metrics never leave the register file during a launch.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "kernels.h"
+#include "viterbi_codes.h"
+
+namespace vh {
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// polynomials of src/main.cpp:367,377,386,396
+struct Poly27 { static constexpr int v[2] = {0x6d, 0x4f}; };
+struct Poly47 { static constexpr int v[4] = {121, 117, 91, 111}; };
+struct Poly29 { static constexpr int v[2] = {0x1af, 0x11d}; };
+struct Poly49 { static constexpr int v[4] = {501, 441, 331, 315}; };
+
+constexpr unsigned popcnt_c(unsigned x) {
+    unsigned n = 0;
+    while (x) {
+        n += x & 1u;
+        x >>= 1;
+    }
+    return n;
+}
+template <int NB>
+constexpr unsigned rotl_c(unsigned x, int s) {
+    s %= NB;
+    return s == 0 ? x : (((x << s) | (x >> (NB - s))) & ((1u << NB) - 1u));
+}
+// branch-table class of state value j: bit r = parity((2j) & poly[r])   (viterbi27_sse2.cpp:64-67)
+template <class P, int R>
+constexpr unsigned cls_c(unsigned j) {
+    unsigned c = 0;
+    for (int r = 0; r < R; r++) c |= (popcnt_c((2u * j) & (unsigned)P::v[r]) & 1u) << r;
+    return c;
+}
+
+__device__ __forceinline__ unsigned as_u32(u16x2 x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ u16x2 as_v(unsigned x) { return __builtin_bit_cast(u16x2, x); }
+
+template <class C, class P, int LB>
+struct RegsCfg {
+    static constexpr int K = C::K, R = C::R, NB = K - 1;
+    static constexpr int N = 1 << NB, L = 1 << LB, FPW = 64 / L;
+    static constexpr int NR = N / (2 * L);          // packed registers per lane
+    static constexpr int NC = 1 << R;               // branch-table classes
+    static constexpr int NRW = NR < 16 ? NR : 16;   // registers per decision word
+    static constexpr int DW = NR / NRW;             // decision words per lane per row
+    static constexpr int WBYTES = NRW == 16 ? 4 : 2;
+    static constexpr int SW = NB * R / 4;           // symbol dwords per period of NB steps
+    static constexpr bool SAT = C::metric == U8SAT;
+    static_assert((NB * R) % 4 == 0 && NR >= 8 && (NR % 8) == 0, "unsupported geometry");
+};
+
+// packed metric field <-> natural value
+template <bool SAT>
+__device__ __forceinline__ unsigned field_from(int m) { return SAT ? (((unsigned)m << 8) | 0xffu) : ((unsigned)m << 8); }
+__device__ __forceinline__ int field_to(unsigned f) { return (int)((f >> 8) & 0xffu); }
+
+template <bool SAT>
+__device__ __forceinline__ u16x2 madd(u16x2 a, u16x2 t) {
+    if constexpr (SAT) return __builtin_elementwise_add_sat(a, t);  // v_pk_add_u16 clamp == adds_epu8 on the high byte
+    else return a + t;                                               // v_pk_add_u16 wrap  == add_epi8  on the high byte
+}
+
+// One packed add-compare-select: two new states.  `acc` collects decision bit k (low field) / 16+k (high field);
+// for the saturating family the collected bit is the COMPLEMENT of the decision (fixed up once per word).
+template <bool SAT, int KBIT>
+__device__ __forceinline__ u16x2 acs_pk(u16x2 lower, u16x2 upper, unsigned &acc) {
+    const u16x2 one = {(unsigned short)(1u << KBIT), (unsigned short)(1u << KBIT)};
+    if constexpr (SAT) {
+        // min_epu8(upper,lower); decision = (min == upper) <=> upper <= lower       spiral47.cpp:224-227
+        const u16x2 z = __builtin_elementwise_sub_sat(upper, lower);  // 0 <=> upper <= lower; else a multiple of 256
+        acc |= as_u32(__builtin_elementwise_min(z, one));
+        return __builtin_elementwise_min(lower, upper);
+    } else {
+        // decision = (int8)(lower-upper) > 0, survivor = decision ? upper : lower    viterbi27_sse2.cpp:155-158
+        const i16x2 diff = (i16x2)(lower - upper);
+        const i16x2 zero = {0, 0};
+        const u16x2 pd = (u16x2)__builtin_elementwise_max(diff, zero);  // 0 or a multiple of 256 in [0x100,0x7f00]
+        acc |= as_u32(__builtin_elementwise_min(pd, one));
+        return lower - pd;
+    }
+}
+
+template <int CTRL>
+__device__ __forceinline__ u16x2 dpp_quad(u16x2 x) {
+    return as_v((unsigned)__builtin_amdgcn_mov_dpp((int)as_u32(x), CTRL, 0xf, 0xf, true));
+}
+template <int BIT>
+__device__ __forceinline__ u16x2 dpp_xor(u16x2 x) {
+    static_assert(BIT == 0 || BIT == 1, "lane stages stay inside a quad");
+    if constexpr (BIT == 0) return dpp_quad<0xB1>(x);  // quad_perm [1,0,3,2]
+    else return dpp_quad<0x4E>(x);                     // quad_perm [2,3,0,1]
+}
+
+// branch metrics of one step for all 2^R classes, as a 16-bit field value (t << 8), per lane
+template <class C, int NC>
+__device__ __forceinline__ void branch_fields(const unsigned (&s)[C::R], unsigned (&T)[NC]) {
+    if constexpr (C::metric == U8MOD) {
+        // t = ((a0+a1+1)>>1)>>4                                                   viterbi27_sse2.cpp:137-146
+        const unsigned x0 = s[0] ^ 255u, x1 = s[1] ^ 255u;
+        const unsigned a0[2] = {s[0], x0}, a1[2] = {s[1], x1};
+#pragma unroll
+        for (int c = 0; c < 4; c++) T[c] = ((a0[c & 1] + a1[c >> 1] + 1u) >> 5) << 8;
+    } else {
+        // t = (sum_r ((a_r>>2)&63)) >> 2; (s^255)>>2 == 63-(s>>2)                     spiral47.cpp:164-219
+        unsigned g[4], h[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            g[r] = s[r] >> 2;
+            h[r] = g[r] ^ 63u;
+        }
+        unsigned p01[4], p23[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            p01[c] = ((c & 1) ? h[0] : g[0]) + ((c & 2) ? h[1] : g[1]);
+            p23[c] = ((c & 1) ? h[2] : g[2]) + ((c & 2) ? h[3] : g[3]);
+        }
+#pragma unroll
+        for (int c = 0; c < 16; c++) T[c] = ((p01[c & 3] + p23[c >> 2]) >> 2) << 8;
+    }
+}
+
+template <class C, class P, int LB>
+struct RegsStep {
+    using G = RegsCfg<C, P, LB>;
+    static constexpr int NB = G::NB, R = G::R, NR = G::NR, NC = G::NC, L = G::L;
+    static constexpr bool SAT = G::SAT;
+    static constexpr unsigned COMP2 = ((unsigned)C::bm_comp << 8) * 0x10001u;
+
+    // One trellis step at phase PHI (absolute row index mod NB).  M: packed metrics; sraw: this step's R symbols;
+    // lam: lane index inside the frame's lane group; words: decision words of this row.
+    template <int PHI>
+    static __device__ __forceinline__ void run(u16x2 (&M)[NR], const unsigned (&sraw)[R], unsigned lam, unsigned (&words)[G::DW]) {
+        constexpr int b = NB - 1 - PHI;  // position bit paired at this phase
+        // per-lane class offset from the lane bits of the position (linear in GF(2)); fold it into the symbols
+        unsigned s[R];
+        {
+            unsigned cl = 0;
+            static_for<LB>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                if constexpr (i != b) {
+                    constexpr unsigned ci = cls_c<P, R>(rotl_c<NB>(1u << i, PHI));
+                    cl ^= ((lam >> i) & 1u) ? ci : 0u;
+                }
+            });
+#pragma unroll
+            for (int r = 0; r < R; r++) s[r] = sraw[r] ^ (((cl >> r) & 1u) ? 255u : 0u);
+        }
+        unsigned T[NC];
+        branch_fields<C, NC>(s, T);
+        unsigned acc[NR / 8];
+#pragma unroll
+        for (int i = 0; i < NR / 8; i++) acc[i] = 0;
+
+        if constexpr (b > LB) {
+            // ---- register-bit stage: partner lives in another register of the same lane
+            constexpr int rb = b - (LB + 1);
+            constexpr unsigned ch = cls_c<P, R>(rotl_c<NB>(1u << LB, PHI));
+            unsigned TP[NC], TQ[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                TP[c] = T[c] | (T[c ^ ch] << 16);
+                TQ[c] = COMP2 - TP[c];
+            }
+            static_for<NR / 2>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                constexpr int r0 = ((i >> rb) << (rb + 1)) | (i & ((1 << rb) - 1));
+                constexpr int r1 = r0 | (1 << rb);
+                constexpr unsigned cr = cls_c<P, R>(rotl_c<NB>((unsigned)r0 << (LB + 1), PHI));
+                const u16x2 A = M[r0], B = M[r1];
+                const u16x2 t = as_v(TP[cr]), tc = as_v(TQ[cr]);
+                const u16x2 m0 = madd<SAT>(A, t), m1 = madd<SAT>(B, tc), m2 = madd<SAT>(A, tc), m3 = madd<SAT>(B, t);
+                M[r0] = acs_pk<SAT, (r0 & 7)>(m0, m1, acc[r0 >> 3]);
+                M[r1] = acs_pk<SAT, (r1 & 7)>(m2, m3, acc[r1 >> 3]);
+            });
+        } else if constexpr (b == LB) {
+            // ---- half stage: old[j] is the low field, old[j+H] the high field of the same register
+            static_for<NR>([&](auto I) {
+                constexpr int r0 = decltype(I)::value;
+                constexpr unsigned cr = cls_c<P, R>(rotl_c<NB>((unsigned)r0 << (LB + 1), PHI));
+                const unsigned t = T[cr], tc = ((unsigned)C::bm_comp << 8) - t;
+                const u16x2 A = M[r0];
+                const u16x2 U = madd<SAT>(A, as_v(t | (tc << 16)));   // (m0, m1)
+                const u16x2 V = madd<SAT>(A, as_v(tc | (t << 16)));   // (m2, m3)
+                const u16x2 lower = {U.x, V.x}, upper = {U.y, V.y};
+                M[r0] = acs_pk<SAT, (r0 & 7)>(lower, upper, acc[r0 >> 3]);
+            });
+        } else {
+            // ---- lane stage: partner register lives in lane ^ (1<<b) of the same quad
+            constexpr unsigned ch = cls_c<P, R>(rotl_c<NB>(1u << LB, PHI));
+            unsigned TP[NC], TQ[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                TP[c] = T[c] | (T[c ^ ch] << 16);
+                TQ[c] = COMP2 - TP[c];
+            }
+            const bool isY = (lam >> b) & 1u;  // this lane holds old[j+H] and will hold new[2j+1]
+            static_for<NR>([&](auto I) {
+                constexpr int r0 = decltype(I)::value;
+                constexpr unsigned cr = cls_c<P, R>(rotl_c<NB>((unsigned)r0 << (LB + 1), PHI));
+                const u16x2 own = M[r0];
+                const u16x2 oth = dpp_xor<(b < 0 ? 0 : b)>(own);
+                const u16x2 a = madd<SAT>(own, as_v(TP[cr]));   // X: m0 = old[j]+t     Y: m3 = old[j+H]+t
+                const u16x2 q = madd<SAT>(oth, as_v(TQ[cr]));   // X: m1 = old[j+H]+t'  Y: m2 = old[j]+t'
+                const u16x2 lower = isY ? q : a, upper = isY ? a : q;
+                M[r0] = acs_pk<SAT, (r0 & 7)>(lower, upper, acc[r0 >> 3]);
+            });
+        }
+
+        // ---- decision words: bit (rho % NRW) + NRW*half of word rho / NRW
+        if constexpr (G::NRW == 16) {
+#pragma unroll
+            for (int w = 0; w < G::DW; w++) {
+                const unsigned v = acc[2 * w] | (acc[2 * w + 1] << 8);
+                words[w] = SAT ? ~v : v;
+            }
+        } else {
+            const unsigned v = (acc[0] & 0xffu) | ((acc[0] >> 8) & 0xff00u);
+            words[0] = SAT ? (v ^ 0xffffu) : v;
+        }
+
+        // ---- renormalisation (spiral only): if new[0] > thr subtract the frame minimum, saturating
+        if constexpr (C::renorm) {
+            unsigned v0 = as_u32(M[0]) & 0xffffu;  // state 0 always sits at position 0: register 0, low field, lane 0
+            if constexpr (LB == 1) v0 = (unsigned)__builtin_amdgcn_mov_dpp((int)v0, 0xA0, 0xf, 0xf, true);  // [0,0,2,2]
+            if constexpr (LB == 2) v0 = (unsigned)__builtin_amdgcn_mov_dpp((int)v0, 0x00, 0xf, 0xf, true);  // [0,0,0,0]
+            const bool fire = v0 > (((unsigned)C::renorm_thr << 8) | 0xffu);  // spiral47.cpp:313
+            u16x2 mn = M[0];
+#pragma unroll
+            for (int i = 1; i < NR; i++) mn = __builtin_elementwise_min(mn, M[i]);
+            const u16x2 sw = {mn.y, mn.x};
+            mn = __builtin_elementwise_min(mn, sw);
+            if constexpr (LB >= 1) mn = __builtin_elementwise_min(mn, dpp_xor<0>(mn));
+            if constexpr (LB >= 2) mn = __builtin_elementwise_min(mn, dpp_xor<1>(mn));
+            const u16x2 amt = as_v(fire ? (as_u32(mn) & 0xff00ff00u) : 0u);
+#pragma unroll
+            for (int i = 0; i < NR; i++) M[i] = __builtin_elementwise_sub_sat(M[i], amt);  // subs_epu8  spiral47.cpp:327-330
+        }
+    }
+};
+
+// symbol fetch: SW dwords covering one period, guarded at both ends of this call's per-frame chunk
+template <int SW>
+__device__ __forceinline__ void load_period(const unsigned char *sp, long off, long lim, bool aligned, unsigned (&d)[SW]) {
+#pragma unroll
+    for (int w = 0; w < SW; w++) {
+        const long o = off + 4 * w;
+        if (aligned && o >= 0 && o + 4 <= lim) {
+            d[w] = *reinterpret_cast<const unsigned *>(sp + o);
+        } else {
+            unsigned v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const long ob = o + k;
+                if (ob >= 0 && ob < lim) v |= (unsigned)sp[ob] << (8 * k);
+            }
+            d[w] = v;
+        }
+    }
+}
+
+template <class C, class P, int LB>
+__global__ __launch_bounds__(64) void acs_regs_kernel(AcsRegsArgs a) {
+    using G = RegsCfg<C, P, LB>;
+    using S = RegsStep<C, P, LB>;
+    constexpr int NB = G::NB, R = G::R, NR = G::NR, L = G::L, FPW = G::FPW, DW = G::DW, SW = G::SW;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned lam = lane & (L - 1);
+    const long wave = blockIdx.x;
+    const long f = wave * FPW + (lane >> LB);
+    const bool fvalid = f < a.nframes;
+    const long fc = fvalid ? f : (long)a.nframes - 1;
+
+    const int row0 = a.row0, row_end = a.row0 + a.nsteps;
+    const int phi0 = row0 % NB;
+    int16_t *gm = a.metrics + fc * (long)G::N;
+
+    // position p holds state rotl^phi(p): load the canonical metrics into the rotated in-register layout
+    u16x2 M[NR];
+#pragma unroll
+    for (int r0 = 0; r0 < NR; r0++) {
+        unsigned fld[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const unsigned p = ((unsigned)r0 << (LB + 1)) | ((unsigned)h << LB) | lam;
+            const unsigned st = phi0 == 0 ? p : (((p << phi0) | (p >> (NB - phi0))) & (G::N - 1));
+            fld[h] = field_from<G::SAT>(gm[st]);
+        }
+        M[r0] = as_v(fld[0] | (fld[1] << 16));
+    }
+
+    const unsigned char *sp = a.syms + fc * (long)a.sym_stride;
+    const long lim = (long)a.nsteps * R;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(a.syms) | a.sym_stride) & 3) == 0 && ((phi0 * R) & 3) == 0;
+    unsigned char *dp = a.dec + ((wave * a.cap_rows + row0) * (long)DW * 64 + lane) * G::WBYTES;
+
+    int rbase = row0 - phi0;
+    unsigned cur[SW], nxt[SW] = {};
+    load_period<SW>(sp, (long)(rbase - row0) * R, lim, aligned, cur);
+    for (; rbase < row_end; rbase += NB) {
+        if (rbase + NB < row_end) load_period<SW>(sp, (long)(rbase + NB - row0) * R, lim, aligned, nxt);
+        static_for<NB>([&](auto I) {
+            constexpr int PHI = decltype(I)::value;
+            const int r = rbase + PHI;
+            if (r >= row0 && r < row_end) {  // wave-uniform
+                unsigned sraw[R];
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    const int idx = PHI * R + q;
+                    sraw[q] = (cur[idx >> 2] >> (8 * (idx & 3))) & 255u;
+                }
+                unsigned words[DW];
+                S::template run<PHI>(M, sraw, lam, words);
+#pragma unroll
+                for (int w = 0; w < DW; w++) {
+                    if constexpr (G::WBYTES == 4) reinterpret_cast<unsigned *>(dp)[w * 64] = words[w];
+                    else reinterpret_cast<unsigned short *>(dp)[w * 64] = (unsigned short)words[w];
+                }
+                dp += (long)DW * 64 * G::WBYTES;
+            }
+        });
+#pragma unroll
+        for (int w = 0; w < SW; w++) cur[w] = nxt[w];
+    }
+
+    if (fvalid) {
+        const int phie = row_end % NB;
+#pragma unroll
+        for (int r0 = 0; r0 < NR; r0++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const unsigned p = ((unsigned)r0 << (LB + 1)) | ((unsigned)h << LB) | lam;
+                const unsigned st = phie == 0 ? p : (((p << phie) | (p >> (NB - phie))) & (G::N - 1));
+                gm[st] = (int16_t)field_to(as_u32(M[r0]) >> (16 * h));
+            }
+        }
+    }
+}
+
+template <class C, class P, int LB>
+static hipError_t launch_regs(const AcsRegsArgs &a, hipStream_t stream) {
+    using G = RegsCfg<C, P, LB>;
+    const int waves = (a.nframes + G::FPW - 1) / G::FPW;
+    hipLaunchKernelGGL((acs_regs_kernel<C, P, LB>), dim3(waves), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+bool regs_poly_supported(int code, const int *poly) {
+    auto eq = [&](const int *ref, int R) {
+        for (int r = 0; r < R; r++)
+            if (poly[r] != ref[r]) return false;
+        return true;
+    };
+    switch (code) {
+    case VHIP_KA9Q27: return eq(Poly27::v, 2);
+    case VHIP_SPIRAL47: return eq(Poly47::v, 4);
+    case VHIP_KA9Q29: return eq(Poly29::v, 2);
+    case VHIP_SPIRAL49: return eq(Poly49::v, 4);
+    }
+    return false;
+}
+
+bool regs_lanes_supported(int code, int lb) {
+    switch (code) {
+    case VHIP_KA9Q27: case VHIP_SPIRAL47: return lb >= 0 && lb <= 2;
+    case VHIP_KA9Q29: case VHIP_SPIRAL49: return lb >= 1 && lb <= 2;
+    }
+    return false;
+}
+
+RegsLayout regs_layout(int code, int lb) {
+    RegsLayout g{};
+    const CodeInfo ci = code_info(code);
+    const int N = 1 << (ci.K - 1), L = 1 << lb;
+    g.lb = lb;
+    g.fpw = 64 / L;
+    g.nr = N / (2 * L);
+    g.nrw = g.nr < 16 ? g.nr : 16;
+    g.dw = g.nr / g.nrw;
+    g.wbytes = g.nrw == 16 ? 4 : 2;
+    return g;
+}
+
+hipError_t launch_acs_regs(int code, int lb, const AcsRegsArgs &a, hipStream_t stream) {
+    switch (code) {
+    case VHIP_KA9Q27:
+        if (lb == 0) return launch_regs<Code27, Poly27, 0>(a, stream);
+        if (lb == 1) return launch_regs<Code27, Poly27, 1>(a, stream);
+        if (lb == 2) return launch_regs<Code27, Poly27, 2>(a, stream);
+        break;
+    case VHIP_SPIRAL47:
+        if (lb == 0) return launch_regs<Code47, Poly47, 0>(a, stream);
+        if (lb == 1) return launch_regs<Code47, Poly47, 1>(a, stream);
+        if (lb == 2) return launch_regs<Code47, Poly47, 2>(a, stream);
+        break;
+    case VHIP_KA9Q29:
+        if (lb == 1) return launch_regs<Code29, Poly29, 1>(a, stream);
+        if (lb == 2) return launch_regs<Code29, Poly29, 2>(a, stream);
+        break;
+    case VHIP_SPIRAL49:
+        if (lb == 1) return launch_regs<Code49, Poly49, 1>(a, stream);
+        if (lb == 2) return launch_regs<Code49, Poly49, 2>(a, stream);
+        break;
+    }
+    return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// chainback over the [group][row][word][lane] decision layout: one thread per frame.
+// Same walk as chainback_viterbi27_sse2 (viterbi27_sse2.cpp:78-105) / chainback_spiral47 (spiral47.cpp:84-121);
+// the decision of new state n at row r sits at position rotr^((r+1) mod NB)(n).
+__global__ __launch_bounds__(64) void chainback_regs_kernel(ChainbackRegsArgs a) {
+    const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= a.nframes) return;
+    const int K = a.K, NB = K - 1, LB = a.lay.lb, L = 1 << LB;
+    const unsigned N = 1u << NB;
+    const long g = f / a.lay.fpw, fl = f % a.lay.fpw;
+    const int add = (NB < 8) ? 8 - NB : 0;
+    const int sub = (NB > 8) ? NB - 8 : 0;
+    unsigned char *out = a.data + f * (long)a.data_stride;
+    unsigned e = (a.endstate % N) << add;
+    const long rowstride = (long)a.lay.dw * 64 * a.lay.wbytes;
+    const unsigned char *base = a.dec + (g * a.cap_rows) * rowstride + (fl * L) * a.lay.wbytes;
+    int rot = (int)((a.nbits - 1 + NB + 1) % NB);  // (r+1) mod NB for the first row visited, r = nbits-1+K-1
+    for (unsigned i = a.nbits; i-- > 0;) {
+        const unsigned st = e >> add;
+        const long r = (long)i + NB;
+        unsigned k = 0;
+        if (r < a.rows_written) {
+            const unsigned p = rot == 0 ? st : (((st >> rot) | (st << (NB - rot))) & (N - 1));
+            const unsigned lam = p & (L - 1), h = (p >> LB) & 1u, rho = p >> (LB + 1);
+            const unsigned w = rho / a.lay.nrw, bit = (rho % a.lay.nrw) + a.lay.nrw * h;
+            const unsigned char *wp = base + r * rowstride + ((long)w * 64 + lam) * a.lay.wbytes;
+            const unsigned word = a.lay.wbytes == 4 ? *reinterpret_cast<const unsigned *>(wp)
+                                                    : *reinterpret_cast<const unsigned short *>(wp);
+            k = (word >> bit) & 1u;
+        }
+        e = (e >> 1) | (k << (K - 2 + add));
+        if ((i & 7u) == 0) out[i >> 3] = (unsigned char)(e >> sub);
+        rot = rot == 0 ? NB - 1 : rot - 1;
+    }
+}
+
+hipError_t launch_chainback_regs(const ChainbackRegsArgs &a, hipStream_t stream) {
+    const int blocks = (a.nframes + 63) / 64;
+    hipLaunchKernelGGL(chainback_regs_kernel, dim3(blocks), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace vh

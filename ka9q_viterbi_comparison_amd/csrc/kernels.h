@@ -22,6 +22,37 @@ hipError_t launch_acs_lds(int code, const AcsLdsArgs &a, hipStream_t stream);
 hipError_t launch_init_metrics(int16_t *metrics, size_t n_per_frame, int nframes, int init_all, int init_start,
                                unsigned start_state, hipStream_t stream);
 
+// ---------------------------------------------------------------- acs_regs.hip (K <= 9, harness polynomials)
+struct RegsLayout {  // decision layout [group][row][word][lane] produced by acs_regs_kernel
+    int lb;      // log2(lanes per frame)
+    int fpw;     // frames per wave (= per group)
+    int nr;      // packed metric registers per lane
+    int nrw;     // registers per decision word (16 -> 32-bit words, 8 -> 16-bit words)
+    int dw;      // decision words per lane per row
+    int wbytes;  // bytes per decision word
+};
+struct AcsRegsArgs {
+    const unsigned char *syms;
+    size_t sym_stride;
+    int nsteps, row0, cap_rows, nframes;
+    unsigned char *dec;   // [groups][cap_rows][dw][64] words
+    int16_t *metrics;     // [nframes][N] canonical path metrics (natural units)
+};
+bool regs_poly_supported(int code, const int *poly);
+bool regs_lanes_supported(int code, int lb);
+RegsLayout regs_layout(int code, int lb);
+hipError_t launch_acs_regs(int code, int lb, const AcsRegsArgs &a, hipStream_t stream);
+struct ChainbackRegsArgs {
+    const unsigned char *dec;
+    RegsLayout lay;
+    int cap_rows, rows_written, nframes;
+    unsigned char *data;
+    size_t data_stride;
+    unsigned nbits, endstate;
+    int K;
+};
+hipError_t launch_chainback_regs(const ChainbackRegsArgs &a, hipStream_t stream);
+
 // ---------------------------------------------------------------- chainback.hip (natural rows)
 struct ChainbackRowsArgs {
     const unsigned char *dec;  // natural rows [nframes][cap_rows][N/8]

@@ -66,6 +66,9 @@ struct vhip_decoder {
     size_t data_stage_bytes = 0;
     int pos = 0;
     std::vector<int> k24_cur;  // per frame: which half of the ping-pong holds the current metrics
+    int regs_lb = 0;           // REGS variant: log2(lanes per frame)
+    vh::RegsLayout lay{};      // REGS variant: decision layout
+    int frames_padded = 0;     // frames rounded up to a whole wave (both decision layouts fit the same buffer)
     size_t total_bytes = 0;
 };
 
@@ -102,6 +105,32 @@ int ensure_stage(unsigned char **buf, size_t *cap, size_t need, size_t *total) {
     *cap = need;
     *total += need;
     return 0;
+}
+
+// lanes per frame for the REGS kernels: the smallest L that still gives >= 2 waves per SIMD on 256 CUs x 4 SIMDs
+int auto_regs_lb(int code, int nframes) {
+    int lb = 0;
+    while (lb < 2 && (long)nframes * (1 << lb) < 64L * 2048) lb++;
+    while (!vh::regs_lanes_supported(code, lb) && lb < 2) lb++;
+    if (const char *e = getenv("VHIP_REGS_LB")) {
+        const int v = atoi(e);
+        if (vh::regs_lanes_supported(code, v)) lb = v;
+    }
+    return lb;
+}
+
+int auto_variant(const vhip_decoder *p) {
+    if (p->code == VHIP_KA9Q224) return VHIP_VARIANT_HBM;
+    if (p->K <= 9 && vh::regs_poly_supported(p->code, p->poly)) return VHIP_VARIANT_REGS;
+    return VHIP_VARIANT_LDS;
+}
+
+void apply_variant(vhip_decoder *p, int variant, int lb) {
+    p->variant = variant;
+    if (variant == VHIP_VARIANT_REGS) {
+        p->regs_lb = lb;
+        p->lay = vh::regs_layout(p->code, lb);
+    }
 }
 
 // K=24: run `steps` trellis steps of frame f speculatively, replaying after each renormalisation event.
@@ -185,9 +214,10 @@ vhip_decoder *vhip_create(int code, const int *poly, int len, int nframes) {
     // rows: ka9q27/29/615 and spiral allocate len+K-1 (viterbi27_sse2.cpp:72, spiral47.cpp:79), ka9q224 len (:61)
     p->cap_rows = (code == VHIP_KA9Q224) ? len : len + ci.K - 1;
     p->row_bytes = p->N / 8;
-    p->variant = (code == VHIP_KA9Q224) ? VHIP_VARIANT_HBM : VHIP_VARIANT_LDS;
+    p->frames_padded = (code == VHIP_KA9Q224) ? nframes : ((nframes + 63) / 64) * 64;
+    apply_variant(p, auto_variant(p), auto_regs_lb(code, nframes));
     (void)hipGetDevice(&p->device);
-    const size_t dec_bytes = (size_t)nframes * (size_t)p->cap_rows * p->row_bytes;
+    const size_t dec_bytes = (size_t)p->frames_padded * (size_t)p->cap_rows * p->row_bytes;
     const size_t met_bytes = (size_t)nframes * p->N * sizeof(int16_t) * (code == VHIP_KA9Q224 ? 2 : 1);
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&p->d_dec), dec_bytes ? dec_bytes : 16);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_metrics), met_bytes);
@@ -238,10 +268,20 @@ int vhip_sync(vhip_decoder *p) {
 int vhip_set_variant(vhip_decoder *p, int variant) {
     if (!p) return fail("set_variant: NULL handle");
     if (p->pos != 0) return fail("set_variant: only before the first update after init");
-    if (variant == VHIP_VARIANT_AUTO) variant = (p->code == VHIP_KA9Q224) ? VHIP_VARIANT_HBM : VHIP_VARIANT_LDS;
-    if (p->code == VHIP_KA9Q224 && variant != VHIP_VARIANT_HBM) return fail("set_variant: K=24 supports only HBM");
-    if (p->code != VHIP_KA9Q224 && variant != VHIP_VARIANT_LDS) return fail("set_variant: unsupported for this code");
-    p->variant = variant;
+    // bits 8.. optionally carry 1 + log2(lanes per frame) for the REGS kernels
+    const int lb_req = (variant >> 8) - 1;
+    variant &= 0xff;
+    if (variant == VHIP_VARIANT_AUTO) variant = auto_variant(p);
+    if (p->code == VHIP_KA9Q224) {
+        if (variant != VHIP_VARIANT_HBM) return fail("set_variant: K=24 supports only HBM");
+    } else if (variant == VHIP_VARIANT_REGS) {
+        if (p->K > 9 || !vh::regs_poly_supported(p->code, p->poly))
+            return fail("set_variant: REGS kernels exist for K<=9 with the harness polynomials only");
+        if (lb_req >= 0 && !vh::regs_lanes_supported(p->code, lb_req)) return fail("set_variant: unsupported lanes per frame");
+    } else if (variant != VHIP_VARIANT_LDS) {
+        return fail("set_variant: unsupported for this code");
+    }
+    apply_variant(p, variant, lb_req >= 0 ? lb_req : auto_regs_lb(p->code, p->nframes));
     return 0;
 }
 int vhip_get_variant(const vhip_decoder *p) { return p ? p->variant : -1; }
@@ -280,6 +320,17 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
     if (p->code == VHIP_KA9Q224) {
         for (int f = 0; f < p->nframes; f++)
             if (k24_update_frame(p, f, d_syms + (size_t)f * sym_stride, steps, row0) != 0) return -1;
+    } else if (p->variant == VHIP_VARIANT_REGS) {
+        vh::AcsRegsArgs a;
+        a.syms = d_syms;
+        a.sym_stride = sym_stride;
+        a.nsteps = steps;
+        a.row0 = row0;
+        a.cap_rows = p->cap_rows;
+        a.nframes = p->nframes;
+        a.dec = p->d_dec;
+        a.metrics = p->d_metrics;
+        HIP_TRY(vh::launch_acs_regs(p->code, p->regs_lb, a, p->stream));
     } else {
         vh::AcsLdsArgs a;
         a.syms = d_syms;
@@ -300,6 +351,21 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
 int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbits, unsigned int endstate) {
     if (!p) return fail("chainback: NULL handle");
     if (nbits == 0) return 0;
+    if (p->variant == VHIP_VARIANT_REGS) {
+        vh::ChainbackRegsArgs a;
+        a.dec = p->d_dec;
+        a.lay = p->lay;
+        a.cap_rows = p->cap_rows;
+        a.rows_written = p->pos;
+        a.nframes = p->nframes;
+        a.data = d_data;
+        a.data_stride = (nbits + 7) / 8;
+        a.nbits = nbits;
+        a.endstate = endstate;
+        a.K = p->K;
+        HIP_TRY(vh::launch_chainback_regs(a, p->stream));
+        return 0;
+    }
     vh::ChainbackRowsArgs a;
     a.dec = p->d_dec;
     a.cap_rows = p->cap_rows;
@@ -351,6 +417,29 @@ int vhip_read_decision_rows(vhip_decoder *p, int frame, int row0, int nrows, uns
     if (frame < 0 || frame >= p->nframes || row0 < 0 || nrows < 0 || row0 + nrows > p->cap_rows)
         return fail("read_decision_rows: out of range");
     HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->variant == VHIP_VARIANT_REGS) {
+        // [group][row][word][lane] -> natural bitmap: new state n of row r sits at position rotr^((r+1) mod NB)(n)
+        const vh::RegsLayout &L = p->lay;
+        const int NB = p->K - 1, lanes = 1 << L.lb;
+        const size_t rowstride = (size_t)L.dw * 64 * L.wbytes;
+        const size_t g = frame / L.fpw, fl = frame % L.fpw;
+        std::vector<unsigned char> raw((size_t)nrows * rowstride);
+        HIP_TRY(hipMemcpy(raw.data(), p->d_dec + (g * p->cap_rows + row0) * rowstride, raw.size(), hipMemcpyDeviceToHost));
+        memset(out, 0, (size_t)nrows * p->row_bytes);
+        for (int i = 0; i < nrows; i++) {
+            const int rot = (row0 + i + 1) % NB;
+            for (unsigned n = 0; n < p->N; n++) {
+                const unsigned pos = rot == 0 ? n : (((n >> rot) | (n << (NB - rot))) & (p->N - 1));
+                const unsigned lam = pos & (lanes - 1), h = (pos >> L.lb) & 1u, rho = pos >> (L.lb + 1);
+                const unsigned w = rho / L.nrw, bit = (rho % L.nrw) + L.nrw * h;
+                const unsigned char *wp = raw.data() + i * rowstride + ((size_t)w * 64 + fl * lanes + lam) * L.wbytes;
+                unsigned word = wp[0] | (wp[1] << 8);
+                if (L.wbytes == 4) word |= (wp[2] << 16) | ((unsigned)wp[3] << 24);
+                if ((word >> bit) & 1u) out[(size_t)i * p->row_bytes + (n >> 3)] |= (unsigned char)(1u << (n & 7));
+            }
+        }
+        return 0;
+    }
     HIP_TRY(hipMemcpy(out, p->d_dec + ((size_t)frame * p->cap_rows + row0) * p->row_bytes, (size_t)nrows * p->row_bytes,
                       hipMemcpyDeviceToHost));
     return 0;

@@ -11,7 +11,11 @@ from ka9q_viterbi_comparison_amd import VARIANT_AUTO, VARIANT_LDS, VARIANT_REGS
 from oracle_lib import OracleDecoder
 
 pytestmark = pytest.mark.gpu
-HAVE_REGS = False  # flipped on when acs_regs.hip lands
+
+
+def regs(lb):
+    """REGS variant with 2^lb lanes per frame (bits 8.. of the variant word carry 1+lb)."""
+    return VARIANT_REGS | ((lb + 1) << 8)
 
 
 def variants_for(code):
@@ -19,7 +23,9 @@ def variants_for(code):
         return [VARIANT_AUTO]
     if code == C.KA9Q615:
         return [VARIANT_LDS]
-    return [VARIANT_LDS, VARIANT_REGS] if HAVE_REGS else [VARIANT_LDS]
+    if code in (C.KA9Q27, C.SPIRAL47):
+        return [VARIANT_LDS, regs(0), regs(1), regs(2)]
+    return [VARIANT_LDS, regs(1), regs(2)]
 
 
 def oracle_decode(code, syms, steps, nbits, endstate=0, start=0, splits=None):
