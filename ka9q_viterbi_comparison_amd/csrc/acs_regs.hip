@@ -26,6 +26,7 @@
 // bytes out; the metrics never leave the register file during a launch.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -210,8 +211,8 @@ struct RegsStep {
                 const u16x2 A = M[r0], B = M[r1];
                 const u16x2 t = as_v(TP[cr]), tc = as_v(TQ[cr]);
                 const u16x2 m0 = madd<SAT>(A, t), m1 = madd<SAT>(B, tc), m2 = madd<SAT>(A, tc), m3 = madd<SAT>(B, t);
-                M[r0] = acs_pk<SAT, (r0 & 7)>(m0, m1, acc[r0 >> 3]);
-                M[r1] = acs_pk<SAT, (r1 & 7)>(m2, m3, acc[r1 >> 3]);
+                M[r0] = acs_pk<SAT, (r0 & 7) + 1>(m0, m1, acc[r0 >> 3]);
+                M[r1] = acs_pk<SAT, (r1 & 7) + 1>(m2, m3, acc[r1 >> 3]);
             });
         } else if constexpr (b == LB) {
             // ---- half stage: old[j] is the low field, old[j+H] the high field of the same register
@@ -223,7 +224,7 @@ struct RegsStep {
                 const u16x2 U = madd<SAT>(A, as_v(t | (tc << 16)));   // (m0, m1)
                 const u16x2 V = madd<SAT>(A, as_v(tc | (t << 16)));   // (m2, m3)
                 const u16x2 lower = {U.x, V.x}, upper = {U.y, V.y};
-                M[r0] = acs_pk<SAT, (r0 & 7)>(lower, upper, acc[r0 >> 3]);
+                M[r0] = acs_pk<SAT, (r0 & 7) + 1>(lower, upper, acc[r0 >> 3]);
             });
         } else {
             // ---- lane stage: partner register lives in lane ^ (1<<b) of the same quad
@@ -243,7 +244,7 @@ struct RegsStep {
                 const u16x2 a = madd<SAT>(own, as_v(TP[cr]));   // X: m0 = old[j]+t     Y: m3 = old[j+H]+t
                 const u16x2 q = madd<SAT>(oth, as_v(TQ[cr]));   // X: m1 = old[j+H]+t'  Y: m2 = old[j]+t'
                 const u16x2 lower = isY ? q : a, upper = isY ? a : q;
-                M[r0] = acs_pk<SAT, (r0 & 7)>(lower, upper, acc[r0 >> 3]);
+                M[r0] = acs_pk<SAT, (r0 & 7) + 1>(lower, upper, acc[r0 >> 3]);
             });
         }
 
@@ -251,11 +252,11 @@ struct RegsStep {
         if constexpr (G::NRW == 16) {
 #pragma unroll
             for (int w = 0; w < G::DW; w++) {
-                const unsigned v = acc[2 * w] | (acc[2 * w + 1] << 8);
+                const unsigned v = (acc[2 * w] >> 1) | (acc[2 * w + 1] << 7);  // accumulators use bits 1..8 / 17..24
                 words[w] = SAT ? ~v : v;
             }
         } else {
-            const unsigned v = (acc[0] & 0xffu) | ((acc[0] >> 8) & 0xff00u);
+            const unsigned v = ((acc[0] >> 1) & 0xffu) | ((acc[0] >> 9) & 0xff00u);
             words[0] = SAT ? (v ^ 0xffffu) : v;
         }
 
@@ -279,30 +280,62 @@ struct RegsStep {
     }
 };
 
-// symbol fetch: SW dwords covering one period, guarded at both ends of this call's per-frame chunk
+// symbol fetch, slow form: SW dwords covering one period, byte-assembled and guarded at both ends of this
+// call's per-frame chunk (partial first/last period, or a chunk that is not 4-byte aligned)
 template <int SW>
-__device__ __forceinline__ void load_period(const unsigned char *sp, long off, long lim, bool aligned, unsigned (&d)[SW]) {
+__device__ __forceinline__ void load_period_guarded(const unsigned char *sp, long off, long lim, unsigned (&d)[SW]) {
 #pragma unroll
     for (int w = 0; w < SW; w++) {
-        const long o = off + 4 * w;
-        if (aligned && o >= 0 && o + 4 <= lim) {
-            d[w] = *reinterpret_cast<const unsigned *>(sp + o);
-        } else {
-            unsigned v = 0;
+        unsigned v = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const long ob = o + k;
-                if (ob >= 0 && ob < lim) v |= (unsigned)sp[ob] << (8 * k);
-            }
-            d[w] = v;
+        for (int k = 0; k < 4; k++) {
+            const long ob = off + 4 * w + k;
+            if (ob >= 0 && ob < lim) v |= (unsigned)sp[ob] << (8 * k);
         }
+        d[w] = v;
     }
+}
+// fast form: the whole period lies inside the chunk and is dword aligned -> SW plain dword loads (merged by the
+// compiler into dwordx2/x3/x4), no branches, so the loads stay in flight under the previous period's arithmetic
+template <int SW>
+__device__ __forceinline__ void load_period_fast(const unsigned char *sp, long off, unsigned (&d)[SW]) {
+    const unsigned *p = reinterpret_cast<const unsigned *>(sp + off);
+#pragma unroll
+    for (int w = 0; w < SW; w++) d[w] = p[w];
+}
+
+// one period = NB consecutive trellis steps at phases 0..NB-1; GUARD: skip steps outside [row0,row_end)
+template <class C, class P, int LB, bool GUARD, int NR_, int SW_>
+__device__ __forceinline__ void run_period(u16x2 (&M)[NR_], const unsigned (&cur)[SW_], int rbase, int row0, int row_end,
+                                           unsigned lam, unsigned char *&dp) {
+    using G = RegsCfg<C, P, LB>;
+    using S = RegsStep<C, P, LB>;
+    constexpr int R = G::R, DW = G::DW;
+    static_for<G::NB>([&](auto I) {
+        constexpr int PHI = decltype(I)::value;
+        const int r = rbase + PHI;
+        if (!GUARD || (r >= row0 && r < row_end)) {  // wave-uniform
+            unsigned sraw[R];
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const int idx = PHI * R + q;
+                sraw[q] = (cur[idx >> 2] >> (8 * (idx & 3))) & 255u;
+            }
+            unsigned words[DW];
+            S::template run<PHI>(M, sraw, lam, words);
+#pragma unroll
+            for (int w = 0; w < DW; w++) {
+                if constexpr (G::WBYTES == 4) reinterpret_cast<unsigned *>(dp)[w * 64] = words[w];
+                else reinterpret_cast<unsigned short *>(dp)[w * 64] = (unsigned short)words[w];
+            }
+            dp += (long)DW * 64 * G::WBYTES;
+        }
+    });
 }
 
 template <class C, class P, int LB>
 __global__ __launch_bounds__(64) void acs_regs_kernel(AcsRegsArgs a) {
     using G = RegsCfg<C, P, LB>;
-    using S = RegsStep<C, P, LB>;
     constexpr int NB = G::NB, R = G::R, NR = G::NR, L = G::L, FPW = G::FPW, DW = G::DW, SW = G::SW;
     const unsigned lane = threadIdx.x & 63u;
     const unsigned lam = lane & (L - 1);
@@ -335,32 +368,31 @@ __global__ __launch_bounds__(64) void acs_regs_kernel(AcsRegsArgs a) {
     unsigned char *dp = a.dec + ((wave * a.cap_rows + row0) * (long)DW * 64 + lane) * G::WBYTES;
 
     int rbase = row0 - phi0;
-    unsigned cur[SW], nxt[SW] = {};
-    load_period<SW>(sp, (long)(rbase - row0) * R, lim, aligned, cur);
-    for (; rbase < row_end; rbase += NB) {
-        if (rbase + NB < row_end) load_period<SW>(sp, (long)(rbase + NB - row0) * R, lim, aligned, nxt);
-        static_for<NB>([&](auto I) {
-            constexpr int PHI = decltype(I)::value;
-            const int r = rbase + PHI;
-            if (r >= row0 && r < row_end) {  // wave-uniform
-                unsigned sraw[R];
+    while (rbase < row_end) {
+        const bool full = rbase >= row0 && rbase + NB <= row_end;
+        if (!(aligned && full)) {
+            // slow period: partial head / tail, or unaligned symbols
+            unsigned cur[SW];
+            load_period_guarded<SW>(sp, (long)(rbase - row0) * R, lim, cur);
+            run_period<C, P, LB, true>(M, cur, rbase, row0, row_end, lam, dp);
+            rbase += NB;
+            continue;
+        }
+        // fast run over all remaining full periods; the next period's symbols are fetched while this one computes
+        const int nfull = (row_end - rbase) / NB;
+        long off = (long)(rbase - row0) * R;
+        const long last_off = off + (long)(nfull - 1) * NB * R;
+        unsigned cur[SW], nxt[SW];
+        load_period_fast<SW>(sp, off, cur);
+        for (int i = 0; i < nfull; i++) {
+            const long noff = off + NB * R < last_off ? off + NB * R : last_off;  // clamped: no branch around the load
+            load_period_fast<SW>(sp, noff, nxt);
+            run_period<C, P, LB, false>(M, cur, rbase, row0, row_end, lam, dp);
 #pragma unroll
-                for (int q = 0; q < R; q++) {
-                    const int idx = PHI * R + q;
-                    sraw[q] = (cur[idx >> 2] >> (8 * (idx & 3))) & 255u;
-                }
-                unsigned words[DW];
-                S::template run<PHI>(M, sraw, lam, words);
-#pragma unroll
-                for (int w = 0; w < DW; w++) {
-                    if constexpr (G::WBYTES == 4) reinterpret_cast<unsigned *>(dp)[w * 64] = words[w];
-                    else reinterpret_cast<unsigned short *>(dp)[w * 64] = (unsigned short)words[w];
-                }
-                dp += (long)DW * 64 * G::WBYTES;
-            }
-        });
-#pragma unroll
-        for (int w = 0; w < SW; w++) cur[w] = nxt[w];
+            for (int w = 0; w < SW; w++) cur[w] = nxt[w];
+            off += NB * R;
+            rbase += NB;
+        }
     }
 
     if (fvalid) {
@@ -481,8 +513,95 @@ __global__ __launch_bounds__(64) void chainback_regs_kernel(ChainbackRegsArgs a)
     }
 }
 
+// Pipelined form of the same walk.  In this layout the bytes holding a frame's decisions for row r do not
+// depend on the state (all N/8 bytes of the row belong to the frame's own L lanes), so the loads of D rows are
+// issued together, ahead of the serial state recurrence; the dependent part of a step is then a register select
+// plus shifts.  HBM bytes read = the whole decision history (N/8 per frame-row) instead of one word per step.
+template <int K, int LB, int D>
+__global__ __launch_bounds__(64) void chainback_regs_pipe_kernel(ChainbackRegsArgs a) {
+    constexpr int NB = K - 1, L = 1 << LB;
+    constexpr unsigned N = 1u << NB;
+    constexpr int NR = N / (2 * L), NRW = NR < 16 ? NR : 16, DW = NR / NRW, WB = NRW == 16 ? 4 : 2;
+    constexpr int CHB = L * WB;           // contiguous bytes of this frame per (row, word index)
+    constexpr int CHD = CHB >= 4 ? CHB / 4 : 1;  // dwords loaded per chunk (a 2-byte chunk is loaded as u16)
+    constexpr int QD = DW * CHD;          // dwords per frame-row held in registers
+    constexpr int FPW = 64 / L;
+    constexpr int add = (NB < 8) ? 8 - NB : 0, sub = (NB > 8) ? NB - 8 : 0;
+    const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= a.nframes) return;
+    const long g = f / FPW, fl = f % FPW;
+    unsigned char *out = a.data + f * (long)a.data_stride;
+    constexpr long rowstride = (long)DW * 64 * WB;
+    const unsigned char *base = a.dec + (g * a.cap_rows) * rowstride + (fl * L) * WB;
+    unsigned e = (a.endstate % N) << add;
+    int rot = (int)(a.nbits % NB);  // (r+1) mod NB at the first row visited, r = nbits-1 + NB
+
+    auto step = [&](unsigned i, const unsigned (&q)[QD], bool have) {
+        const unsigned st = e >> add;
+        unsigned k = 0;
+        if (have) {
+            const unsigned p = rot == 0 ? st : (((st >> rot) | (st << (NB - rot))) & (N - 1));
+            const unsigned lam = p & (L - 1), h = (p >> LB) & 1u, rho = p >> (LB + 1);
+            const unsigned w = rho / NRW, bit = (rho % NRW) + NRW * h;
+            const unsigned byteoff = w * CHB + lam * WB;       // inside the frame's QD*4 bytes (chunks packed per w)
+            const unsigned qi = CHB >= 4 ? byteoff / 4 : w;    // 2-byte chunks occupy one register each
+            const unsigned sh = (CHB >= 4 ? (byteoff & 3u) * 8 : 0) + bit;
+            unsigned word = q[0];
+#pragma unroll
+            for (int t = 1; t < QD; t++) word = (qi == (unsigned)t) ? q[t] : word;
+            k = (word >> sh) & 1u;
+        }
+        e = (e >> 1) | (k << (K - 2 + add));
+        if ((i & 7u) == 0) out[i >> 3] = (unsigned char)(e >> sub);
+        rot = rot == 0 ? NB - 1 : rot - 1;
+    };
+    auto load_row = [&](long r, unsigned (&q)[QD]) {
+        const unsigned char *rp = base + r * rowstride;
+#pragma unroll
+        for (int w = 0; w < DW; w++) {
+            const unsigned char *cp = rp + (long)w * 64 * WB;
+            if constexpr (CHB >= 4) {
+#pragma unroll
+                for (int d = 0; d < CHD; d++) q[w * CHD + d] = reinterpret_cast<const unsigned *>(cp)[d];
+            } else {
+                q[w] = *reinterpret_cast<const unsigned short *>(cp);
+            }
+        }
+    };
+
+    unsigned i = a.nbits;
+    // rows at or beyond rows_written read as zero: walk them one at a time (uniform across the launch)
+    while (i > 0 && (long)(i - 1) + NB >= a.rows_written) {
+        --i;
+        unsigned q[QD] = {};
+        step(i, q, false);
+    }
+    while (i >= (unsigned)D) {
+        unsigned q[D][QD];
+#pragma unroll
+        for (int d = 0; d < D; d++) load_row((long)(i - 1 - d) + NB, q[d]);
+#pragma unroll
+        for (int d = 0; d < D; d++) step(i - 1 - d, q[d], true);
+        i -= D;
+    }
+    while (i > 0) {
+        --i;
+        unsigned q[QD];
+        load_row((long)i + NB, q);
+        step(i, q, true);
+    }
+}
+
 hipError_t launch_chainback_regs(const ChainbackRegsArgs &a, hipStream_t stream) {
     const int blocks = (a.nframes + 63) / 64;
+    const bool pipe = getenv("VHIP_CHAINBACK_SIMPLE") == nullptr;
+#define VH_CB(KK, LBB, DD)                                                                                       \
+    if (pipe && a.K == KK && a.lay.lb == LBB) {                                                                  \
+        hipLaunchKernelGGL((chainback_regs_pipe_kernel<KK, LBB, DD>), dim3(blocks), dim3(64), 0, stream, a);     \
+        return hipGetLastError();                                                                                \
+    }
+    VH_CB(7, 0, 16) VH_CB(7, 1, 16) VH_CB(7, 2, 16) VH_CB(9, 1, 8) VH_CB(9, 2, 8)
+#undef VH_CB
     hipLaunchKernelGGL(chainback_regs_kernel, dim3(blocks), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
