@@ -31,6 +31,7 @@ import torch.distributed as dist  # noqa: E402
 
 from ka9q_viterbi_comparison_amd import HipViterbi, codes as C, count_bit_errors_dev, gen_frames_dev, noise_q12  # noqa: E402
 from ka9q_viterbi_comparison_amd.decoder import gen_frames_host  # noqa: E402
+from ka9q_viterbi_comparison_amd.sharding import barrier as shard_barrier, max_over_ranks, sum_over_ranks, weak_range  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -48,47 +49,39 @@ def cpu_baseline(spec, payload_bits, budget_s=12.0):
     """Times the CPU decoder on this host on a bounded sample of the same workload: the genuine reference objects
     (oracle/_ref/libref.so, built from /root/reference in the build container) when present -> kind "reference";
     else the plain-C restatement -> kind "port".  One frame per call, reset+update+chainback per frame
-    (src/main.cpp:257-280), first on 1 thread, then on all host cores (ctypes releases the GIL)."""
+    (src/main.cpp:257-280), timed inside C (oracle/ref_shim.cpp ref_bench_loop): first 1 thread, then one decoder
+    per host core in parallel Python threads (ctypes releases the GIL for the whole loop)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
 
     use_ref = ol.have_ref()
     payload_bytes = payload_bits // 8
     steps = payload_bits + spec.K - 1
-    nsample = 256
+    nsample = 64 if spec.K < 15 else (8 if spec.K == 15 else 1)
     nq = noise_q12(spec.R, C.SOFT_AMP, spec.ebn0_db)
     _, syms = gen_frames_host(spec, 0xC0FFEE, 0, nsample, payload_bytes, C.SOFT_AMP_Q16, nq)
+    syms = np.ascontiguousarray(syms)
     w32 = spec.code == C.KA9Q615  # SURVEY.md §0.3
 
     def make():
         return ol.RefDecoder(spec.code, spec.poly, steps, w32=w32) if use_ref else ol.OracleDecoder(spec.code, spec.poly, steps)
 
     def work(dec, seconds):
-        lib, h, code = dec.lib, dec.h, spec.code
-        out = np.zeros(payload_bytes, dtype=np.uint8)
-        outp = out.ctypes.data_as(ctypes.c_void_p)
-        n, t0 = 0, time.perf_counter()
-        while True:
-            s = syms[n % nsample]
-            sp = s.ctypes.data_as(ctypes.c_void_p)
-            if use_ref:
-                lib.ref_init(code, h, 0)
-                lib.ref_update(code, h, sp, steps)
-                lib.ref_chainback(code, h, outp, payload_bits, 0)
-            else:
-                lib.vo_init(h, 0)
-                lib.vo_update_blk(h, sp, steps)
-                lib.vo_chainback(h, outp, payload_bits, 0)
-            n += 1
-            if (n & 15) == 0 and time.perf_counter() - t0 >= seconds:
-                break
-        return n, time.perf_counter() - t0
+        el = ctypes.c_double(0.0)
+        sp = syms.ctypes.data_as(ctypes.c_void_p)
+        if use_ref:
+            n = dec.lib.ref_bench_loop(spec.code, dec.h, sp, nsample, syms.shape[1], steps, payload_bits, seconds, ctypes.byref(el))
+        else:
+            n = dec.lib.vo_bench_loop(dec.h, sp, nsample, syms.shape[1], steps, payload_bits, seconds, ctypes.byref(el))
+        return n, el.value
 
-    cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
-        pass
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))  # the GPU box gives one GPU a 16-core share
+    if spec.K == 24:
+        cores = min(cores, 4)      # each K=24 handle holds 32 MiB of metrics + 1 MiB per step
     decs = [make() for _ in range(cores)]  # created serially: the reference's table init is not thread-safe
     n1, t1 = work(decs[0], budget_s * 0.4)
     single = n1 * steps * spec.R / t1 / 1e6
@@ -106,9 +99,8 @@ def cpu_baseline(spec, payload_bits, budget_s=12.0):
         "cores": cores,
         "kind": "reference" if use_ref else "port",
         "single_thread_value": round(single, 3),
-        "sample": f"{n1}+{nall} one-frame decodes (reset+update+chainback) of K={spec.K} r=1/{spec.R} x {payload_bits} bits, "
-                  f"AWGN Eb/N0={spec.ebn0_db} dB, {budget_s:.0f} s budget; value = all {cores} threads, "
-                  f"single_thread_value = 1 thread",
+        "sample": f"{n1} (1 thread) + {nall} ({cores} threads) one-frame decodes (reset+update+chainback) of K={spec.K} "
+                  f"r=1/{spec.R} x {payload_bits} bits, AWGN Eb/N0={spec.ebn0_db} dB, {budget_s:.0f} s budget",
     }
 
 
@@ -161,7 +153,8 @@ def main():
     else:
         amp_q16, nq = C.SOFT_AMP_Q16, noise_q12(spec.R, C.SOFT_AMP, ebn0)
     # synthetic frames generated on the device, distinct per rank (frame ids rank*frames ...)
-    gen_frames_dev(spec, 0x5EED, rank * frames, frames, payload_bytes, amp_q16, nq, d_payload, d_syms, stream.cuda_stream)
+    frame_lo, _ = weak_range(frames, rank)
+    gen_frames_dev(spec, 0x5EED, frame_lo, frames, payload_bytes, amp_q16, nq, d_payload, d_syms, stream.cuda_stream)
     dec = HipViterbi(args.code, nsteps, nframes=frames, variant=args.variant, stream=stream.cuda_stream)
     # K=24's own chainback call convention needs nbits+K-1 to decode correctly; the harness call
     # (nbits = payload bits) is what is timed, as in the reference.
@@ -179,10 +172,7 @@ def main():
             ev[2].record(stream)
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        shard_barrier(dev)
 
     for _ in range(args.warmup):
         one_pass()
@@ -193,15 +183,13 @@ def main():
         one_pass(events[i])
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, dev)
 
     upd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
     cb_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
     # correctness guard outside the timed region: decoded bytes vs transmitted payload (BER over the batch)
     nerr = count_bit_errors_dev(d_out, d_payload, frames * payload_bytes, stream.cuda_stream) if spec.K != 24 else -1
+    nerr = sum_over_ranks(nerr, dev) if spec.K != 24 else -1
 
     if rank == 0:
         total_syms = frames * nsteps * spec.R * n_gpus
@@ -238,7 +226,7 @@ def main():
             "update_ms": round(upd_ms, 4),
             "chainback_ms": round(cb_ms, 4),
             "bit_errors": int(nerr),
-            "payload_bits_total": frames * payload_bits,
+            "payload_bits_total": frames * payload_bits * n_gpus,
             "roofline": {"bound": "hbm", "kernel": "acs_update", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": abytes},

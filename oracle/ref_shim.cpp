@@ -14,6 +14,9 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <chrono>
+#include <vector>
+
 #include "viterbi224_sse2.h"
 #include "viterbi27_sse2.h"
 #include "viterbi29_sse2.h"
@@ -184,6 +187,30 @@ void ref_metrics(int code, void *p, int32_t *out) {
     case C_SPIRAL49: case C_SPIRAL29: { auto *m = (const uint8_t *)((spiral_peek<256> *)p)->old_metrics; for (int i = 0; i < 256; i++) out[i] = m[i]; break; }
     case C_SPIRAL615: { auto *m = (const uint8_t *)((spiral_peek<16384> *)p)->old_metrics; for (int i = 0; i < 16384; i++) out[i] = m[i]; break; }
     }
+}
+
+// Timed decode loop for bench.py's cpu_baseline leg: one frame per call, reset + update + chainback per frame
+// exactly as src/main.cpp:257-280 does, cycling over `nsample` frames until `seconds` have elapsed.  Runs entirely
+// in C so that Python threads (GIL released by ctypes) measure the decoder, not the interpreter.
+long ref_bench_loop(int code, void *p, const unsigned char *syms, int nsample, long frame_stride, int steps, unsigned nbits,
+                    double seconds, double *elapsed) {
+    std::vector<unsigned char> out((nbits + 7) / 8 + 8), tmp((size_t)frame_stride);
+    const auto t0 = std::chrono::steady_clock::now();
+    long n = 0;
+    double el = 0;
+    for (;;) {
+        memcpy(tmp.data(), syms + (size_t)(n % nsample) * (size_t)frame_stride, (size_t)frame_stride);
+        ref_init(code, p, 0);
+        ref_update(code, p, tmp.data(), steps);
+        ref_chainback(code, p, out.data(), nbits, 0);
+        n++;
+        if ((n & 7) == 0 || steps > 100000) {
+            el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (el >= seconds) break;
+        }
+    }
+    *elapsed = el;
+    return n;
 }
 
 }  // extern "C"

@@ -13,6 +13,7 @@
 #include <limits.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 enum { M_U8MOD = 0, M_U8SAT = 1, M_I16SAT = 2 };
 enum { BM_KA9Q_AVG = 0, BM_KA9Q_SUM = 1, BM_SPIRAL_SUM6 = 2, BM_SPIRAL_AVG = 3 };
@@ -341,4 +342,27 @@ size_t vo_encode(int K, int R, const int *poly, const unsigned char *payload, si
         }
     }
     return o;
+}
+
+/* Timed decode loop for bench.py's cpu_baseline leg (kind "port"): reset + update + chainback per frame as
+ * src/main.cpp:257-280, cycling over nsample frames until `seconds` have elapsed. */
+long vo_bench_loop(vo_decoder *p, const unsigned char *syms, int nsample, long frame_stride, int steps, unsigned nbits,
+                   double seconds, double *elapsed) {
+    unsigned char *out = (unsigned char *)malloc((nbits + 7) / 8 + 8);
+    struct timespec t0, t1;
+    long n = 0;
+    double el = 0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {
+        vo_init(p, 0);
+        vo_update_blk(p, syms + (size_t)(n % nsample) * (size_t)frame_stride, steps);
+        vo_chainback(p, out, nbits, 0);
+        n++;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        el = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+        if (el >= seconds) break;
+    }
+    free(out);
+    *elapsed = el;
+    return n;
 }

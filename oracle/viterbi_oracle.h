@@ -67,6 +67,10 @@ int vo_renorm_count(const vo_decoder *p);
 size_t vo_encode(int K, int R, const int *poly, const unsigned char *payload, size_t nbytes,
                  unsigned char *coded_bits);
 
+/* bench.py cpu_baseline leg only: timed reset+update+chainback loop, returns frames decoded. */
+long vo_bench_loop(vo_decoder *p, const unsigned char *syms, int nsample, long frame_stride, int steps, unsigned nbits,
+                   double seconds, double *elapsed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,8 @@ def oracle():
         lib.vo_code_R.argtypes = [C.c_int]
         lib.vo_encode.restype = C.c_size_t
         lib.vo_encode.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.vo_bench_loop.restype = C.c_long
+        lib.vo_bench_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_uint, C.c_double, C.POINTER(C.c_double)]
         _oracle = lib
     return _oracle
 
@@ -66,6 +68,8 @@ def ref(w32=False):
         lib.ref_metrics.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         lib.ref_metrics.restype = None
         lib.ref_sizeof_long.restype = C.c_int
+        lib.ref_bench_loop.restype = C.c_long
+        lib.ref_bench_loop.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_uint, C.c_double, C.POINTER(C.c_double)]
         _refs[path] = lib
     return _refs[path]
 
