@@ -1,0 +1,331 @@
+// acs_k15.hip -- production ACS update kernel for K=15 r=1/6 (ka9q i16 saturating family).
+//
+// Replaces update_viterbi615_blk_sse2 (ka9q_libfec_port/viterbi615_sse2.cpp:104-191) for the harness
+// polynomials (src/main.cpp:405).
+//
+// One 128-thread workgroup (2 waves) per frame; several workgroups per CU.  The 16384 i16 metrics of a frame use
+// the same in-place rotating trellis as acs_regs.hip (position p holds state rotl^phi(p) before the step of phase
+// phi = row mod 14; the butterfly partner differs in position bit 13-phi), but the positions are split
+//      7 "free" bits held in registers (128 positions = 64 packed VGPRs per thread)  x  7 bits = thread id.
+// Phases 0..6 pair position bits 13..7, phases 7..13 pair bits 6..0, so a thread runs SEVEN trellis steps on
+// registers alone, then the workgroup transposes through a 32 KiB LDS image (free bits <-> thread bits) and runs
+// the other seven.  LDS traffic is 2 x 32 KiB per 7 steps instead of per step, and no metric touches HBM.
+//
+// Arithmetic (viterbi615_sse2.cpp:132-148): t = sum of six (sym ^ table) terms, t' = 1530 - t, adds_epi16,
+// min_epi16, decision = (min == upper) i.e. tie -> upper; packed as v_pk_add_i16 clamp / v_pk_min_i16, with the
+// decision taken from the sign of the saturating difference lower - upper (sign set <=> decision 0).
+// Branch metrics: the 64 table classes factor as TA[c & 7] + TB[c >> 3] (two 8-entry tables per step); the class
+// contribution of the thread-id bits is folded into the symbols (XOR with 255), so table indices are static.
+// Renormalisation (viterbi615_sse2.cpp:160-183) is exact and immediate: thread 0 owns state 0 (position 0 in every
+// phase), publishes new[0] >= 20017 through LDS behind the per-step barrier, and the workgroup min-reduces and
+// subtracts with 16-bit wrap-around.
+//
+// Decision layout: row r = 512 words [w][thread], bit (rho & 15) + 16*half of word rho >> 4, where (thread, rho,
+// half) follow from position rotr^((r+1) mod 14)(n) of new state n and the phase group of r (see chainback below).
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "kernels.h"
+#include "viterbi_codes.h"
+
+namespace vh {
+namespace k15 {
+
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int K = 15, R = 6, NB = 14, N = 1 << NB;
+constexpr int THREADS = 128, NR = 64;
+constexpr int POLY[6] = {042631, 047245, 056507, 073363, 077267, 064537};  // src/main.cpp:405
+
+template <class F, int... Is>
+__device__ __forceinline__ void sfor_impl(F &&f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int NN, class F>
+__device__ __forceinline__ void sfor(F &&f) {
+    sfor_impl(f, std::make_integer_sequence<int, NN>{});
+}
+
+constexpr unsigned popc(unsigned x) {
+    unsigned n = 0;
+    while (x) {
+        n += x & 1u;
+        x >>= 1;
+    }
+    return n;
+}
+constexpr unsigned rotl14(unsigned x, int s) {
+    s %= NB;
+    return s == 0 ? x : (((x << s) | (x >> (NB - s))) & (N - 1u));
+}
+// branch-table class of state j: bit r = parity((2j) & poly[r])                  viterbi615_sse2.cpp:52-56
+constexpr unsigned cls(unsigned j) {
+    unsigned c = 0;
+    for (int r = 0; r < R; r++) c |= (popc((2u * j) & (unsigned)POLY[r]) & 1u) << r;
+    return c;
+}
+
+__device__ __forceinline__ unsigned as_u32(i16x2 x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ i16x2 as_v(unsigned x) { return __builtin_bit_cast(i16x2, x); }
+
+// packed ACS for two new states; acc collects the COMPLEMENT of the decision at bit KB / 16+KB
+template <int KB>
+__device__ __forceinline__ i16x2 acs(i16x2 lower, i16x2 upper, unsigned &acc) {
+    const i16x2 w = __builtin_elementwise_sub_sat(lower, upper);  // < 0  <=>  lower < upper  <=>  decision 0
+    const i16x2 full = w >> 15;                                   // 0xffff where decision is 0
+    constexpr unsigned mask = (1u << KB) | (1u << (16 + KB));
+    acc = (as_u32(full) & mask) | (acc & ~mask);                  // v_bfi_b32
+    return __builtin_elementwise_min(lower, upper);               // min_epi16
+}
+
+// One trellis step at phase PHI on the 128 positions this thread holds.
+template <int PHI>
+__device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R], unsigned tid, unsigned (&words)[4]) {
+    constexpr int b = NB - 1 - PHI;            // position bit paired in this phase
+    constexpr bool GA = b >= 7;                // group A: free bits 7..13, thread bits 0..6; group B: the reverse
+    constexpr int kf = GA ? b - 7 : b;         // local free-bit index of the paired bit (0 = the half bit)
+    constexpr int FSH = GA ? 7 : 0;            // local position q <-> position bits: p_q = q << FSH
+    constexpr int TSH = GA ? 0 : 7;            // thread bits <-> position bits:     p_t = tid << TSH
+
+    // class offset of the thread-id bits, folded into the symbols (conditional complement)
+    unsigned cl = 0;
+    sfor<7>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        constexpr unsigned ci = cls(rotl14(1u << (i + TSH), PHI));
+        cl ^= ((tid >> i) & 1u) ? ci : 0u;
+    });
+    unsigned s[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) s[r] = sraw[r] ^ (((cl >> r) & 1u) ? 255u : 0u);
+
+    // t(c) = TA[c & 7] + TB[c >> 3]                                                  viterbi615_sse2.cpp:132-135
+    unsigned TA[8], TB[8];
+    {
+        const unsigned x0 = s[0] ^ 255u, x1 = s[1] ^ 255u, x2 = s[2] ^ 255u;
+        const unsigned y0 = s[3] ^ 255u, y1 = s[4] ^ 255u, y2 = s[5] ^ 255u;
+        const unsigned a01[4] = {s[0] + s[1], x0 + s[1], s[0] + x1, x0 + x1};
+        const unsigned b01[4] = {s[3] + s[4], y0 + s[4], s[3] + y1, y0 + y1};
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            TA[c] = a01[c & 3] + ((c & 4) ? x2 : s[2]);
+            TB[c] = b01[c & 3] + ((c & 4) ? y2 : s[5]);
+        }
+    }
+    unsigned acc[4] = {0, 0, 0, 0};
+    constexpr unsigned COMP = (unsigned)Code615::bm_comp;
+
+    if constexpr (kf > 0) {
+        constexpr int rb = kf - 1;
+        constexpr unsigned ch = cls(rotl14(1u << FSH, PHI));  // class of the half bit (local bit 0)
+        unsigned TAp[8], TBp[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            TAp[c] = TA[c] | (TA[c ^ (ch & 7u)] << 16);
+            TBp[c] = TB[c] | (TB[c ^ (ch >> 3)] << 16);
+        }
+        sfor<NR / 2>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            constexpr int r0 = ((i >> rb) << (rb + 1)) | (i & ((1 << rb) - 1));
+            constexpr int r1 = r0 | (1 << rb);
+            constexpr unsigned cr = cls(rotl14(((unsigned)r0 << 1) << FSH, PHI));
+            const unsigned tp = TAp[cr & 7u] + TBp[cr >> 3];       // both fields <= 1530: no carry between them
+            const unsigned tq = COMP * 0x10001u - tp;              // t' = 1530 - t in both fields
+            const i16x2 A = M[r0], B = M[r1];
+            const i16x2 m0 = __builtin_elementwise_add_sat(A, as_v(tp)), m1 = __builtin_elementwise_add_sat(B, as_v(tq));
+            const i16x2 m2 = __builtin_elementwise_add_sat(A, as_v(tq)), m3 = __builtin_elementwise_add_sat(B, as_v(tp));
+            M[r0] = acs<(r0 & 15)>(m0, m1, acc[r0 >> 4]);
+            M[r1] = acs<(r1 & 15)>(m2, m3, acc[r1 >> 4]);
+        });
+    } else {
+        // half stage: old[j] is the low field, old[j+H] the high field of the same register
+        sfor<NR>([&](auto I) {
+            constexpr int r0 = decltype(I)::value;
+            constexpr unsigned cr = cls(rotl14(((unsigned)r0 << 1) << FSH, PHI));
+            const unsigned t = TA[cr & 7u] + TB[cr >> 3], tc = COMP - t;
+            const i16x2 A = M[r0];
+            const i16x2 U = __builtin_elementwise_add_sat(A, as_v(t | (tc << 16)));  // (m0, m1)
+            const i16x2 V = __builtin_elementwise_add_sat(A, as_v(tc | (t << 16)));  // (m2, m3)
+            const i16x2 lower = {U.x, V.x}, upper = {U.y, V.y};
+            M[r0] = acs<(r0 & 15)>(lower, upper, acc[r0 >> 4]);
+        });
+    }
+#pragma unroll
+    for (int w = 0; w < 4; w++) words[w] = ~acc[w];
+}
+
+struct Smem {
+    alignas(16) int16_t img[N];   // 32 KiB: metrics by position
+    int flag[2];      // renormalisation request of the current step (double-buffered by row parity)
+    int red[2];       // per-wave minima
+};
+
+__global__ __launch_bounds__(THREADS) void acs_k15_kernel(AcsK15Args a) {
+    __shared__ Smem sm;
+    const unsigned tid = threadIdx.x;
+    const long f = blockIdx.x;
+    const int row0 = a.row0, row_end = a.row0 + a.nsteps;
+    const int phi0 = row0 % NB;
+    int16_t *gm = a.metrics + f * (long)N;
+    for (unsigned p = tid; p < (unsigned)N; p += THREADS) {
+        const unsigned st = phi0 == 0 ? p : (((p << phi0) | (p >> (NB - phi0))) & (N - 1u));
+        sm.img[p] = gm[st];
+    }
+    const unsigned char *sp = a.syms + f * (long)a.sym_stride;
+    const long lim = (long)a.nsteps * R;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(a.syms) | a.sym_stride) & 3) == 0 && ((phi0 * R) & 3) == 0;
+    unsigned *drow = reinterpret_cast<unsigned *>(a.dec) + (f * a.cap_rows + row0) * 512L + tid;
+    __syncthreads();
+
+    i16x2 M[NR];
+    for (int rbase = row0 - phi0; rbase < row_end; rbase += NB) {
+        // this period's 14 x 6 symbol bytes (uniform across the workgroup)
+        unsigned cur[21];
+        const long off = (long)(rbase - row0) * R;
+        if (aligned && off >= 0 && off + 84 <= lim) {
+            const unsigned *p32 = reinterpret_cast<const unsigned *>(sp + off);
+#pragma unroll
+            for (int w = 0; w < 21; w++) cur[w] = p32[w];
+        } else {
+#pragma unroll
+            for (int w = 0; w < 21; w++) {
+                unsigned v = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const long ob = off + 4 * w + k;
+                    if (ob >= 0 && ob < lim) v |= (unsigned)sp[ob] << (8 * k);
+                }
+                cur[w] = v;
+            }
+        }
+        auto run_group = [&](auto GSEL) {
+            constexpr int G = decltype(GSEL)::value;  // 0: phases 0..6 (free bits 7..13), 1: phases 7..13 (free bits 0..6)
+            // gather this thread's 128 positions
+            if constexpr (G == 0) {
+#pragma unroll
+                for (int r0 = 0; r0 < NR; r0++) {
+                    const unsigned lo = (unsigned short)sm.img[((2 * r0) << 7) | tid];
+                    const unsigned hi = (unsigned short)sm.img[((2 * r0 + 1) << 7) | tid];
+                    M[r0] = as_v(lo | (hi << 16));
+                }
+            } else {
+                const uint4 *src = reinterpret_cast<const uint4 *>(&sm.img[tid << 7]);
+#pragma unroll
+                for (int q = 0; q < NR / 4; q++) {
+                    const uint4 v = src[q];
+                    M[4 * q] = as_v(v.x);
+                    M[4 * q + 1] = as_v(v.y);
+                    M[4 * q + 2] = as_v(v.z);
+                    M[4 * q + 3] = as_v(v.w);
+                }
+            }
+            __syncthreads();  // every thread has its registers before anyone overwrites the image
+            sfor<7>([&](auto I) {
+                constexpr int PHI = G * 7 + decltype(I)::value;
+                const int r = rbase + PHI;
+                if (r >= row0 && r < row_end) {  // workgroup-uniform
+                    unsigned sraw[R];
+#pragma unroll
+                    for (int q = 0; q < R; q++) {
+                        const int idx = PHI * R + q;
+                        sraw[q] = (cur[idx >> 2] >> (8 * (idx & 3))) & 255u;
+                    }
+                    unsigned words[4];
+                    stage<PHI>(M, sraw, tid, words);
+#pragma unroll
+                    for (int w = 0; w < 4; w++) drow[w * 128] = words[w];
+                    drow += 512;
+                    // renormalise when new[0] >= SHRT_MAX-12750; state 0 is position 0 = thread 0, register 0, low field
+                    if (tid == 0) sm.flag[r & 1] = ((int)(short)(as_u32(M[0]) & 0xffffu)) >= Code615::renorm_thr;
+                    __syncthreads();
+                    if (sm.flag[r & 1]) {
+                        i16x2 mn = M[0];
+#pragma unroll
+                        for (int i = 1; i < NR; i++) mn = __builtin_elementwise_min(mn, M[i]);
+                        int m = min((int)mn.x, (int)mn.y);
+#pragma unroll
+                        for (int o = 32; o >= 1; o >>= 1) m = min(m, __shfl_xor(m, o));
+                        if ((tid & 63u) == 0) sm.red[tid >> 6] = m;
+                        __syncthreads();
+                        m = min(sm.red[0], sm.red[1]);
+                        const unsigned adj = (unsigned)(m + 32768) & 0xffffu;  // min - SHRT_MIN       :166-172
+                        const u16x2 av = {(unsigned short)adj, (unsigned short)adj};
+#pragma unroll
+                        for (int i = 0; i < NR; i++) M[i] = (i16x2)((u16x2)M[i] - av);  // sub_epi16 wraps   :181-182
+                    }
+                }
+            });
+            // scatter back to the position image
+            if constexpr (G == 0) {
+#pragma unroll
+                for (int r0 = 0; r0 < NR; r0++) {
+                    sm.img[((2 * r0) << 7) | tid] = M[r0].x;
+                    sm.img[((2 * r0 + 1) << 7) | tid] = M[r0].y;
+                }
+            } else {
+                uint4 *dst = reinterpret_cast<uint4 *>(&sm.img[tid << 7]);
+#pragma unroll
+                for (int q = 0; q < NR / 4; q++)
+                    dst[q] = make_uint4(as_u32(M[4 * q]), as_u32(M[4 * q + 1]), as_u32(M[4 * q + 2]), as_u32(M[4 * q + 3]));
+            }
+            __syncthreads();
+        };
+        run_group(std::integral_constant<int, 0>{});
+        run_group(std::integral_constant<int, 1>{});
+    }
+
+    const int phie = row_end % NB;
+    for (unsigned p = tid; p < (unsigned)N; p += THREADS) {
+        const unsigned st = phie == 0 ? p : (((p << phie) | (p >> (NB - phie))) & (N - 1u));
+        gm[st] = sm.img[p];
+    }
+}
+
+// chainback over the K=15 layout; same walk as chainback_viterbi615_sse2 (viterbi615_sse2.cpp:65-91, 32-bit word
+// semantics -- SURVEY.md §0.3).  One thread per frame; one dependent 4-byte load per decoded bit.
+__global__ __launch_bounds__(64) void chainback_k15_kernel(ChainbackRowsArgs a) {
+    const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= a.nframes) return;
+    constexpr int sub = NB - 8;
+    unsigned char *out = a.data + f * (long)a.data_stride;
+    const unsigned *rows = reinterpret_cast<const unsigned *>(a.dec) + f * (long)a.cap_rows * 512L;
+    unsigned e = a.endstate % N;
+    int rot = (int)(a.nbits % NB);  // (r+1) mod 14 at the first row visited (r = nbits-1 + 14)
+    for (unsigned i = a.nbits; i-- > 0;) {
+        const long r = (long)i + NB;
+        unsigned k = 0;
+        if (r < a.rows_written) {
+            const unsigned p = rot == 0 ? e : (((e >> rot) | (e << (NB - rot))) & (N - 1u));
+            const int phi = rot == 0 ? NB - 1 : rot - 1;  // phase of row r
+            const unsigned t = phi < 7 ? (p & 127u) : (p >> 7), q = phi < 7 ? (p >> 7) : (p & 127u);
+            const unsigned rho = q >> 1, h = q & 1u;
+            const unsigned word = rows[r * 512L + (rho >> 4) * 128 + t];
+            k = (word >> ((rho & 15u) + 16u * h)) & 1u;
+        }
+        e = (k << (K - 2)) | (e >> 1);                                   // viterbi615_sse2.cpp:87
+        if ((i & 7u) == 0) out[i >> 3] = (unsigned char)(e >> sub);      // :88
+        rot = rot == 0 ? NB - 1 : rot - 1;
+    }
+}
+
+}  // namespace k15
+
+bool k15_poly_supported(const int *poly) {
+    for (int r = 0; r < 6; r++)
+        if (poly[r] != k15::POLY[r]) return false;
+    return true;
+}
+
+hipError_t launch_acs_k15(const AcsK15Args &a, hipStream_t stream) {
+    hipLaunchKernelGGL(k15::acs_k15_kernel, dim3(a.nframes), dim3(k15::THREADS), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_chainback_k15(const ChainbackRowsArgs &a, hipStream_t stream) {
+    hipLaunchKernelGGL(k15::chainback_k15_kernel, dim3((a.nframes + 63) / 64), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace vh

@@ -53,6 +53,19 @@ struct ChainbackRegsArgs {
 };
 hipError_t launch_chainback_regs(const ChainbackRegsArgs &a, hipStream_t stream);
 
+// ---------------------------------------------------------------- acs_k15.hip (K = 15, harness polynomials)
+struct AcsK15Args {
+    const unsigned char *syms;
+    size_t sym_stride;
+    int nsteps, row0, cap_rows, nframes;
+    unsigned char *dec;   // [nframes][cap_rows][4][128] words
+    int16_t *metrics;     // [nframes][16384] canonical path metrics
+};
+struct ChainbackRowsArgs;
+bool k15_poly_supported(const int *poly);
+hipError_t launch_acs_k15(const AcsK15Args &a, hipStream_t stream);
+hipError_t launch_chainback_k15(const ChainbackRowsArgs &a, hipStream_t stream);
+
 // ---------------------------------------------------------------- chainback.hip (natural rows)
 struct ChainbackRowsArgs {
     const unsigned char *dec;  // natural rows [nframes][cap_rows][N/8]

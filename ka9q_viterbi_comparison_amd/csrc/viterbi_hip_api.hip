@@ -122,12 +122,13 @@ int auto_regs_lb(int code, int nframes) {
 int auto_variant(const vhip_decoder *p) {
     if (p->code == VHIP_KA9Q224) return VHIP_VARIANT_HBM;
     if (p->K <= 9 && vh::regs_poly_supported(p->code, p->poly)) return VHIP_VARIANT_REGS;
+    if (p->code == VHIP_KA9Q615 && vh::k15_poly_supported(p->poly)) return VHIP_VARIANT_REGS;
     return VHIP_VARIANT_LDS;
 }
 
 void apply_variant(vhip_decoder *p, int variant, int lb) {
     p->variant = variant;
-    if (variant == VHIP_VARIANT_REGS) {
+    if (variant == VHIP_VARIANT_REGS && p->code != VHIP_KA9Q615) {
         p->regs_lb = lb;
         p->lay = vh::regs_layout(p->code, lb);
     }
@@ -274,6 +275,8 @@ int vhip_set_variant(vhip_decoder *p, int variant) {
     if (variant == VHIP_VARIANT_AUTO) variant = auto_variant(p);
     if (p->code == VHIP_KA9Q224) {
         if (variant != VHIP_VARIANT_HBM) return fail("set_variant: K=24 supports only HBM");
+    } else if (variant == VHIP_VARIANT_REGS && p->code == VHIP_KA9Q615) {
+        if (!vh::k15_poly_supported(p->poly)) return fail("set_variant: the K=15 register kernel needs the harness polynomials");
     } else if (variant == VHIP_VARIANT_REGS) {
         if (p->K > 9 || !vh::regs_poly_supported(p->code, p->poly))
             return fail("set_variant: REGS kernels exist for K<=9 with the harness polynomials only");
@@ -320,6 +323,17 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
     if (p->code == VHIP_KA9Q224) {
         for (int f = 0; f < p->nframes; f++)
             if (k24_update_frame(p, f, d_syms + (size_t)f * sym_stride, steps, row0) != 0) return -1;
+    } else if (p->variant == VHIP_VARIANT_REGS && p->code == VHIP_KA9Q615) {
+        vh::AcsK15Args a;
+        a.syms = d_syms;
+        a.sym_stride = sym_stride;
+        a.nsteps = steps;
+        a.row0 = row0;
+        a.cap_rows = p->cap_rows;
+        a.nframes = p->nframes;
+        a.dec = p->d_dec;
+        a.metrics = p->d_metrics;
+        HIP_TRY(vh::launch_acs_k15(a, p->stream));
     } else if (p->variant == VHIP_VARIANT_REGS) {
         vh::AcsRegsArgs a;
         a.syms = d_syms;
@@ -351,6 +365,21 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
 int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbits, unsigned int endstate) {
     if (!p) return fail("chainback: NULL handle");
     if (nbits == 0) return 0;
+    if (p->variant == VHIP_VARIANT_REGS && p->code == VHIP_KA9Q615) {
+        vh::ChainbackRowsArgs a;
+        a.dec = p->d_dec;
+        a.cap_rows = p->cap_rows;
+        a.rows_written = p->pos;
+        a.nframes = p->nframes;
+        a.data = d_data;
+        a.data_stride = (nbits + 7) / 8;
+        a.nbits = nbits;
+        a.endstate = endstate;
+        a.K = p->K;
+        a.k224 = 0;
+        HIP_TRY(vh::launch_chainback_k15(a, p->stream));
+        return 0;
+    }
     if (p->variant == VHIP_VARIANT_REGS) {
         vh::ChainbackRegsArgs a;
         a.dec = p->d_dec;
@@ -417,6 +446,24 @@ int vhip_read_decision_rows(vhip_decoder *p, int frame, int row0, int nrows, uns
     if (frame < 0 || frame >= p->nframes || row0 < 0 || nrows < 0 || row0 + nrows > p->cap_rows)
         return fail("read_decision_rows: out of range");
     HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->variant == VHIP_VARIANT_REGS && p->code == VHIP_KA9Q615) {
+        // [row][word][thread] of acs_k15.hip -> natural bitmap
+        const int NB = 14;
+        std::vector<unsigned> raw((size_t)nrows * 512);
+        HIP_TRY(hipMemcpy(raw.data(), p->d_dec + ((size_t)frame * p->cap_rows + row0) * 2048, raw.size() * 4, hipMemcpyDeviceToHost));
+        memset(out, 0, (size_t)nrows * p->row_bytes);
+        for (int i = 0; i < nrows; i++) {
+            const int rot = (row0 + i + 1) % NB, phi = (row0 + i) % NB;
+            for (unsigned n = 0; n < p->N; n++) {
+                const unsigned pos = rot == 0 ? n : (((n >> rot) | (n << (NB - rot))) & (p->N - 1));
+                const unsigned t = phi < 7 ? (pos & 127u) : (pos >> 7), q = phi < 7 ? (pos >> 7) : (pos & 127u);
+                const unsigned rho = q >> 1, h = q & 1u;
+                const unsigned word = raw[(size_t)i * 512 + (rho >> 4) * 128 + t];
+                if ((word >> ((rho & 15u) + 16u * h)) & 1u) out[(size_t)i * p->row_bytes + (n >> 3)] |= (unsigned char)(1u << (n & 7));
+            }
+        }
+        return 0;
+    }
     if (p->variant == VHIP_VARIANT_REGS) {
         // [group][row][word][lane] -> natural bitmap: new state n of row r sits at position rotr^((r+1) mod NB)(n)
         const vh::RegsLayout &L = p->lay;
