@@ -162,7 +162,7 @@ struct Smem {
     int red[2];       // per-wave minima
 };
 
-__global__ __launch_bounds__(THREADS) void acs_k15_kernel(AcsK15Args a) {
+__global__ __launch_bounds__(THREADS, 2) void acs_k15_kernel(AcsK15Args a) {
     __shared__ Smem sm;
     const unsigned tid = threadIdx.x;
     const long f = blockIdx.x;
