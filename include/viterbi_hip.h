@@ -73,8 +73,9 @@ const char *vhip_last_error(void);
 enum vhip_variant {
     VHIP_VARIANT_AUTO = 0,
     VHIP_VARIANT_LDS = 1,   /* one workgroup per frame, metrics ping-pong in LDS, natural decision rows */
-    VHIP_VARIANT_REGS = 2,  /* frames across lanes, packed metrics in VGPRs (K<=9) */
-    VHIP_VARIANT_HBM = 3    /* K=24: metrics tiled through HBM */
+    VHIP_VARIANT_REGS = 2,  /* metrics packed in VGPRs: frames across lanes (K<=9), workgroup per frame (K=15) */
+    VHIP_VARIANT_HBM = 3,   /* K=24: metrics tiled through HBM, one launch per trellis step */
+    VHIP_VARIANT_HBM_FUSED = 4 /* K=24: 4 or 7 trellis steps per pass over the metric array (harness polynomials) */
 };
 int vhip_set_variant(vhip_decoder *p, int variant);
 int vhip_get_variant(const vhip_decoder *p);

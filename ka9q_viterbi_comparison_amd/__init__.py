@@ -12,6 +12,7 @@ from .decoder import (  # noqa: F401
     VARIANT_LDS,
     VARIANT_REGS,
     VARIANT_HBM,
+    VARIANT_HBM_FUSED,
     gen_frames_host,
     gen_frames_dev,
     count_bit_errors_dev,

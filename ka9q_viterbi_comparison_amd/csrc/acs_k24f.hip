@@ -1,0 +1,245 @@
+// acs_k24f.hip -- K=24 r=1/2 ACS update, several trellis steps per pass over the 16 MiB metric array.
+//
+// Replaces update_viterbi224_blk_sse2 (ka9q_libfec_port/viterbi224_sse2.cpp:135-258) for the harness polynomials
+// (src/main.cpp:415).  acs_k24.hip moves 32 MiB of metrics through HBM for every trellis step; here the in-place
+// rotating trellis (position p holds state rotl^phi(p), phi = row mod 23; the butterfly partner of phase phi
+// differs in position bit 22-phi) lets a thread keep 128 positions (64 packed VGPRs) in registers and run every
+// phase whose partner bit it holds before writing back:
+//      group 0..3 : position bits 22-19, 18-15, 14-11, 10-7   -> 4 steps per pass  (16 strided 16-byte vectors)
+//      group 4    : position bits 6-0                          -> 7 steps per pass  (128 contiguous positions)
+// i.e. 5 passes per 23 steps: 5 x 32 MiB of metric traffic + 23 MiB of decisions instead of 23 x 33 MiB.
+// Passes ping-pong between two buffers (never in place) so that a pass can be replayed: renormalisation
+// (viterbi224_sse2.cpp:226-246) is speculative exactly as in acs_k24.hip -- the thread that owns state 0 (position 0
+// in every phase) raises flags[PENDING] = row+1 when new[0] >= 25000, later passes return at once, and the host
+// replays the raising pass up to that row, renormalises, and continues.
+//
+// Decision row r is a bitmap by POSITION: byte p>>3, bit ((p&1)<<2)|((p>>1)&3); the decision of new state n at row r
+// is at p = rotr^((r+1) mod 23)(n)  (chainback_k24f_kernel below).
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "kernels.h"
+#include "viterbi_codes.h"
+
+namespace vh {
+namespace k24f {
+
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int K = 24, NB = 23;
+constexpr unsigned N = 1u << NB;
+constexpr int NR = 64;
+constexpr int POLY[2] = {062650457, 062650455};  // src/main.cpp:415
+
+template <class F, int... Is>
+__device__ __forceinline__ void sfor_impl(F &&f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int NN, class F>
+__device__ __forceinline__ void sfor(F &&f) {
+    sfor_impl(f, std::make_integer_sequence<int, NN>{});
+}
+constexpr unsigned popc(unsigned x) {
+    unsigned n = 0;
+    while (x) {
+        n += x & 1u;
+        x >>= 1;
+    }
+    return n;
+}
+constexpr unsigned rotl23(unsigned x, int s) {
+    s %= NB;
+    return s == 0 ? x : (((x << s) | (x >> (NB - s))) & (N - 1u));
+}
+constexpr unsigned cls(unsigned j) {  // bit r = parity((2j) & poly[r])                 viterbi224_sse2.cpp:68-73
+    return (popc((2u * j) & (unsigned)POLY[0]) & 1u) | ((popc((2u * j) & (unsigned)POLY[1]) & 1u) << 1);
+}
+__device__ __forceinline__ unsigned as_u32(i16x2 x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ i16x2 as_v(unsigned x) { return __builtin_bit_cast(i16x2, x); }
+
+// group geometry
+constexpr int group_first_phase(int g) { return g < 4 ? 4 * g : 16; }
+constexpr int group_nphases(int g) { return g < 4 ? 4 : 7; }
+constexpr int group_bshift(int g) { return g < 4 ? 19 - 4 * g : 3; }  // lowest vector-index position bit
+
+// packed ACS, tie -> lower (cmpgt_epi16 then min_epi16, viterbi224_sse2.cpp:190-194); acc gets the decision bits
+template <int KB>
+__device__ __forceinline__ i16x2 acs(i16x2 lower, i16x2 upper, unsigned &acc) {
+    const i16x2 w = __builtin_elementwise_sub_sat(upper, lower);  // < 0  <=>  upper < lower  <=>  decision 1
+    const i16x2 full = w >> 15;
+    constexpr unsigned mask = (1u << KB) | (1u << (16 + KB));
+    acc = (as_u32(full) & mask) | (acc & ~mask);
+    return __builtin_elementwise_min(lower, upper);
+}
+
+// One trellis step at phase PHI.  pt = the thread-id part of the position (vector-index and low bits zero).
+// Register rho = 4*v + k holds vector v, elements 2k (low field) and 2k+1 (high field).
+template <int G, int PHI>
+__device__ __forceinline__ void stage(i16x2 (&M)[NR], unsigned s0, unsigned s1, unsigned pt, unsigned (&acc)[4]) {
+    constexpr int b = NB - 1 - PHI;
+    constexpr int BS = group_bshift(G);
+    // static position of register rho, low field
+    auto spos = [](int rho) constexpr -> unsigned { return ((unsigned)(rho >> 2) << BS) | ((unsigned)(rho & 3) << 1); };
+    // class offset of the thread part, folded into the symbols
+    const unsigned jt = PHI == 0 ? pt : (((pt << PHI) | (pt >> (NB - PHI))) & (N - 1u));
+    const unsigned c0 = __popc((2u * jt) & (unsigned)POLY[0]) & 1u, c1 = __popc((2u * jt) & (unsigned)POLY[1]) & 1u;
+    const unsigned a0 = s0 ^ (c0 ? 255u : 0u), a1 = s1 ^ (c1 ? 255u : 0u);
+    const unsigned x0 = a0 ^ 255u, x1 = a1 ^ 255u;
+    const unsigned T[4] = {a0 + a1, x0 + a1, a0 + x1, x0 + x1};  // xor + add   viterbi224_sse2.cpp:159
+    constexpr unsigned COMP = (unsigned)Code224::bm_comp;
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc[i] = 0;
+
+    if constexpr (b >= 1) {
+        // register stage: rho bit 0 <-> position bit 1, rho bit 1 <-> position bit 2, rho bits 2..5 <-> bits BS..BS+3
+        constexpr int rb = (b >= 3) ? (2 + b - BS) : (b - 1);
+        static_assert(rb >= 0 && rb < 6, "phase outside this group");
+        constexpr unsigned ch = cls(rotl23(1u, PHI));  // class of the half bit (position bit 0)
+        unsigned TP[4], TQ[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            TP[c] = T[c] | (T[c ^ ch] << 16);
+            TQ[c] = COMP * 0x10001u - TP[c];
+        }
+        sfor<NR / 2>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            constexpr int r0 = ((i >> rb) << (rb + 1)) | (i & ((1 << rb) - 1));
+            constexpr int r1 = r0 | (1 << rb);
+            constexpr unsigned cr = cls(rotl23(spos(r0), PHI));
+            const i16x2 A = M[r0], B = M[r1];
+            const i16x2 tp = as_v(TP[cr]), tq = as_v(TQ[cr]);
+            const i16x2 m0 = __builtin_elementwise_add_sat(A, tp), m1 = __builtin_elementwise_add_sat(B, tq);  // adds_epi16 :163-166
+            const i16x2 m2 = __builtin_elementwise_add_sat(A, tq), m3 = __builtin_elementwise_add_sat(B, tp);
+            M[r0] = acs<(r0 & 15)>(m0, m1, acc[r0 >> 4]);
+            M[r1] = acs<(r1 & 15)>(m2, m3, acc[r1 >> 4]);
+        });
+    } else {
+        // half stage (position bit 0): old[j] low field, old[j+H] high field
+        sfor<NR>([&](auto I) {
+            constexpr int r0 = decltype(I)::value;
+            constexpr unsigned cr = cls(rotl23(spos(r0), PHI));
+            const unsigned t = T[cr], tc = COMP - t;
+            const i16x2 A = M[r0];
+            const i16x2 U = __builtin_elementwise_add_sat(A, as_v(t | (tc << 16)));
+            const i16x2 V = __builtin_elementwise_add_sat(A, as_v(tc | (t << 16)));
+            const i16x2 lower = {U.x, V.x}, upper = {U.y, V.y};
+            M[r0] = acs<(r0 & 15)>(lower, upper, acc[r0 >> 4]);
+        });
+    }
+}
+
+// decision byte of vector v from the accumulators: bit = half*4 + k
+__device__ __forceinline__ unsigned dec_byte(const unsigned (&acc)[4], int v) {
+    const unsigned a = acc[v >> 2] >> (4 * (v & 3));
+    return (a & 0xfu) | ((a >> 12) & 0xf0u);
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void acs_k24f_pass_kernel(const int16_t *__restrict__ oldm, int16_t *__restrict__ newm,
+                                                            unsigned char *__restrict__ rows, const unsigned char *__restrict__ syms,
+                                                            int rel_row0, int s_lo, int s_hi, int *__restrict__ flags) {
+    // rows/syms point at the first row of THIS pass's phase 0 of the group; rel_row0 = that row's index in the call.
+    // Stages s in [s_lo, s_hi) of the group run; a pending renormalisation of an earlier row cancels the pass.
+    const int pending = flags[K24F_PENDING];
+    if (pending != 0 && pending - 1 < rel_row0 + s_lo) return;
+    constexpr int BS = group_bshift(G), P0 = group_first_phase(G), NP = group_nphases(G);
+    const unsigned u = blockIdx.x * blockDim.x + threadIdx.x;  // 65536 threads
+    unsigned pt;  // thread part of the position
+    if constexpr (G < 4) {
+        const unsigned ulo = u & ((1u << (BS - 3)) - 1u), uhi = u >> (BS - 3);
+        pt = (uhi << (BS + 4)) | (ulo << 3);
+    } else {
+        pt = u << 7;
+    }
+    i16x2 M[NR];
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(oldm + (pt | ((unsigned)v << BS)));
+        M[4 * v] = as_v(q.x);
+        M[4 * v + 1] = as_v(q.y);
+        M[4 * v + 2] = as_v(q.z);
+        M[4 * v + 3] = as_v(q.w);
+    }
+    sfor<NP>([&](auto I) {
+        constexpr int S = decltype(I)::value;
+        constexpr int PHI = P0 + S;
+        if (S >= s_lo && S < s_hi) {  // grid-uniform
+            const unsigned sy0 = syms[2 * S], sy1 = syms[2 * S + 1];
+            unsigned acc[4];
+            stage<G, PHI>(M, sy0, sy1, pt, acc);
+            unsigned char *row = rows + (size_t)S * (N / 8);
+            if constexpr (G < 4) {
+#pragma unroll
+                for (int v = 0; v < 16; v++) row[(pt | ((unsigned)v << BS)) >> 3] = (unsigned char)dec_byte(acc, v);
+            } else {
+                unsigned w[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    w[q] = dec_byte(acc, 4 * q) | (dec_byte(acc, 4 * q + 1) << 8) | (dec_byte(acc, 4 * q + 2) << 16) |
+                           (dec_byte(acc, 4 * q + 3) << 24);
+                *reinterpret_cast<uint4 *>(row + (pt >> 3)) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            if (u == 0) {  // state 0 is position 0 in every phase: thread 0, register 0, low field
+                const int new0 = (int)(short)(as_u32(M[0]) & 0xffffu);
+                if (new0 >= Code224::renorm_thr && flags[K24F_PENDING] == 0) flags[K24F_PENDING] = rel_row0 + S + 1;
+            }
+        }
+    });
+#pragma unroll
+    for (int v = 0; v < 16; v++)
+        *reinterpret_cast<uint4 *>(newm + (pt | ((unsigned)v << BS))) =
+            make_uint4(as_u32(M[4 * v]), as_u32(M[4 * v + 1]), as_u32(M[4 * v + 2]), as_u32(M[4 * v + 3]));
+}
+
+// chainback over position-bitmap rows; same walk as chainback_viterbi224_sse2 (viterbi224_sse2.cpp:79-121): no tail
+// skip, emits the bit that falls off the right end of the state, stores a byte only when nbits%8 == 0.
+__global__ void chainback_k24f_kernel(ChainbackRowsArgs a) {
+    const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= a.nframes) return;
+    unsigned char *out = a.data + f * (long)a.data_stride;
+    const unsigned char *rows = a.dec + f * (long)a.cap_rows * (N / 8);
+    unsigned e = a.endstate & (N - 1u);
+    unsigned dbyte = 0;
+    int rot = (int)(a.nbits % NB);  // (r+1) mod 23 for the first row visited, r = nbits-1
+    for (unsigned i = a.nbits; i-- > 0;) {
+        dbyte = ((e & 1u) << 7) | (dbyte >> 1);
+        if ((i & 7u) == 0) out[i >> 3] = (unsigned char)dbyte;
+        unsigned bit = 0;
+        if ((int)i < a.rows_written) {
+            const unsigned p = rot == 0 ? e : (((e >> rot) | (e << (NB - rot))) & (N - 1u));
+            const unsigned byte = rows[(size_t)i * (N / 8) + (p >> 3)];
+            bit = (byte >> (((p & 1u) << 2) | ((p >> 1) & 3u))) & 1u;
+        }
+        e = (bit << (K - 2)) | (e >> 1);
+        rot = rot == 0 ? NB - 1 : rot - 1;
+    }
+}
+
+}  // namespace k24f
+
+bool k24f_poly_supported(const int *poly) { return poly[0] == k24f::POLY[0] && poly[1] == k24f::POLY[1]; }
+
+// one pass: stages [s_lo, s_hi) of group g; rows/syms are those of the group's first phase
+hipError_t launch_k24f_pass(int g, const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,
+                            int rel_row0, int s_lo, int s_hi, int *flags, hipStream_t stream) {
+    const dim3 grid(65536 / 256), block(256);
+    switch (g) {
+    case 0: hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<0>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags); break;
+    case 1: hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<1>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags); break;
+    case 2: hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<2>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags); break;
+    case 3: hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<3>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags); break;
+    case 4: hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<4>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_chainback_k24f(const ChainbackRowsArgs &a, hipStream_t stream) {
+    hipLaunchKernelGGL(k24f::chainback_k24f_kernel, dim3((a.nframes + 63) / 64), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace vh

@@ -88,6 +88,12 @@ hipError_t launch_k24_step(const int16_t *oldm, int16_t *newm, unsigned char *ro
 hipError_t launch_k24_renorm(int16_t *m, int *flags, hipStream_t stream);  // min-reduce, subtract, clear flags
 hipError_t launch_k24_flags_reset(int *flags, hipStream_t stream);
 
+// ---------------------------------------------------------------- acs_k24f.hip (K = 24, 4/7 steps per pass)
+bool k24f_poly_supported(const int *poly);
+hipError_t launch_k24f_pass(int g, const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,
+                            int rel_row0, int s_lo, int s_hi, int *flags, hipStream_t stream);
+hipError_t launch_chainback_k24f(const ChainbackRowsArgs &a, hipStream_t stream);
+
 // ---------------------------------------------------------------- framegen.hip
 hipError_t launch_gen_frames(int K, int R, const int *poly, uint64_t seed, uint64_t frame0, int nframes,
                              int payload_bytes, int amp_q16, int noise_q12, unsigned char *d_payload,

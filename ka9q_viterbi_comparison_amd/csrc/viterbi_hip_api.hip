@@ -120,7 +120,7 @@ int auto_regs_lb(int code, int nframes) {
 }
 
 int auto_variant(const vhip_decoder *p) {
-    if (p->code == VHIP_KA9Q224) return VHIP_VARIANT_HBM;
+    if (p->code == VHIP_KA9Q224) return vh::k24f_poly_supported(p->poly) ? VHIP_VARIANT_HBM_FUSED : VHIP_VARIANT_HBM;
     if (p->K <= 9 && vh::regs_poly_supported(p->code, p->poly)) return VHIP_VARIANT_REGS;
     if (p->code == VHIP_KA9Q615 && vh::k15_poly_supported(p->poly)) return VHIP_VARIANT_REGS;
     return VHIP_VARIANT_LDS;
@@ -162,6 +162,63 @@ int k24_update_frame(vhip_decoder *p, int f, const unsigned char *d_syms, int st
             HIP_TRY(vh::launch_k24_renorm(buf[cur], p->d_flags, p->stream));
             t = r + 1;
         }
+    }
+    p->k24_cur[f] = cur;
+    return 0;
+}
+
+// K=24 fused passes (acs_k24f.hip): rows are grouped by phase = row mod 23 into passes of 4,4,4,4,7 steps.
+int k24f_update_frame(vhip_decoder *p, int f, const unsigned char *d_syms, int steps, int row0) {
+    const size_t NN = p->N;
+    int16_t *buf[2] = {p->d_metrics + (size_t)f * 2 * NN, p->d_metrics + (size_t)f * 2 * NN + NN};
+    unsigned char *rows = p->d_dec + (size_t)f * p->cap_rows * p->row_bytes;
+    int cur = p->k24_cur[f];
+    struct Pass { int g, s_lo, s_hi, rel, in; };  // rel = index in this call of the row of stage s_lo
+    auto group_of = [](int phi, int &first, int &np) {
+        if (phi < 16) { first = (phi / 4) * 4; np = 4; return phi / 4; }
+        first = 16; np = 7; return 4;
+    };
+    auto launch = [&](const Pass &q) -> int {
+        const long row_g0 = (long)row0 + q.rel - q.s_lo;  // absolute row of the group's phase 0 (may precede row0)
+        HIP_TRY(vh::launch_k24f_pass(q.g, buf[q.in], buf[q.in ^ 1], rows + row_g0 * (long)p->row_bytes,
+                                     d_syms + ((long)q.rel - q.s_lo) * 2, q.rel - q.s_lo, q.s_lo, q.s_hi, p->d_flags, p->stream));
+        return 0;
+    };
+    constexpr int BATCH = 24;  // passes between flag checks
+    int t = 0;                 // next row of this call
+    while (t < steps) {
+        std::vector<Pass> batch;
+        int tt = t, c = cur;
+        while (tt < steps && (int)batch.size() < BATCH) {
+            const int phi = (row0 + tt) % 23;
+            int first, np;
+            const int g = group_of(phi, first, np);
+            Pass q{g, phi - first, std::min(np, phi - first + (steps - tt)), tt, c};
+            if (launch(q) != 0) return -1;
+            batch.push_back(q);
+            tt += q.s_hi - q.s_lo;
+            c ^= 1;
+        }
+        int pending = 0;
+        HIP_TRY(hipMemcpyAsync(&pending, p->d_flags + vh::K24F_PENDING, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        if (pending == 0) {
+            t = tt;
+            cur = c;
+            continue;
+        }
+        const int rr = pending - 1;  // renormalise after this row of the call
+        const Pass *hit = nullptr;
+        for (const Pass &q : batch)
+            if (rr >= q.rel && rr < q.rel + (q.s_hi - q.s_lo)) hit = &q;
+        if (!hit) return fail("K=24 fused: renormalisation flag out of range");
+        HIP_TRY(vh::launch_k24_flags_reset(p->d_flags, p->stream));
+        Pass redo = *hit;
+        redo.s_hi = redo.s_lo + (rr - redo.rel) + 1;  // replay the raising pass up to and including row rr
+        if (launch(redo) != 0) return -1;
+        cur = redo.in ^ 1;
+        HIP_TRY(vh::launch_k24_renorm(buf[cur], p->d_flags, p->stream));  // min-reduce, wrapping subtract, clear flags
+        t = rr + 1;
     }
     p->k24_cur[f] = cur;
     return 0;
@@ -274,7 +331,9 @@ int vhip_set_variant(vhip_decoder *p, int variant) {
     variant &= 0xff;
     if (variant == VHIP_VARIANT_AUTO) variant = auto_variant(p);
     if (p->code == VHIP_KA9Q224) {
-        if (variant != VHIP_VARIANT_HBM) return fail("set_variant: K=24 supports only HBM");
+        if (variant != VHIP_VARIANT_HBM && variant != VHIP_VARIANT_HBM_FUSED) return fail("set_variant: K=24 supports only the HBM variants");
+        if (variant == VHIP_VARIANT_HBM_FUSED && !vh::k24f_poly_supported(p->poly))
+            return fail("set_variant: the fused K=24 kernel needs the harness polynomials");
     } else if (variant == VHIP_VARIANT_REGS && p->code == VHIP_KA9Q615) {
         if (!vh::k15_poly_supported(p->poly)) return fail("set_variant: the K=15 register kernel needs the harness polynomials");
     } else if (variant == VHIP_VARIANT_REGS) {
@@ -321,8 +380,11 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
     if (row0 + steps > p->cap_rows) return fail("update: more trellis steps than the handle was created for");
     const size_t sym_stride = (size_t)nbits * p->R;
     if (p->code == VHIP_KA9Q224) {
-        for (int f = 0; f < p->nframes; f++)
-            if (k24_update_frame(p, f, d_syms + (size_t)f * sym_stride, steps, row0) != 0) return -1;
+        for (int f = 0; f < p->nframes; f++) {
+            const int rc = p->variant == VHIP_VARIANT_HBM_FUSED ? k24f_update_frame(p, f, d_syms + (size_t)f * sym_stride, steps, row0)
+                                                                : k24_update_frame(p, f, d_syms + (size_t)f * sym_stride, steps, row0);
+            if (rc != 0) return -1;
+        }
     } else if (p->variant == VHIP_VARIANT_REGS && p->code == VHIP_KA9Q615) {
         vh::AcsK15Args a;
         a.syms = d_syms;
@@ -365,6 +427,21 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
 int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbits, unsigned int endstate) {
     if (!p) return fail("chainback: NULL handle");
     if (nbits == 0) return 0;
+    if (p->variant == VHIP_VARIANT_HBM_FUSED) {
+        vh::ChainbackRowsArgs a;
+        a.dec = p->d_dec;
+        a.cap_rows = p->cap_rows;
+        a.rows_written = p->pos;
+        a.nframes = p->nframes;
+        a.data = d_data;
+        a.data_stride = (nbits + 7) / 8;
+        a.nbits = nbits;
+        a.endstate = endstate;
+        a.K = p->K;
+        a.k224 = 1;
+        HIP_TRY(vh::launch_chainback_k24f(a, p->stream));
+        return 0;
+    }
     if (p->variant == VHIP_VARIANT_REGS && p->code == VHIP_KA9Q615) {
         vh::ChainbackRowsArgs a;
         a.dec = p->d_dec;
@@ -446,6 +523,22 @@ int vhip_read_decision_rows(vhip_decoder *p, int frame, int row0, int nrows, uns
     if (frame < 0 || frame >= p->nframes || row0 < 0 || nrows < 0 || row0 + nrows > p->cap_rows)
         return fail("read_decision_rows: out of range");
     HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->variant == VHIP_VARIANT_HBM_FUSED) {
+        // position bitmap of acs_k24f.hip -> natural bitmap
+        const int NB = 23;
+        std::vector<unsigned char> raw(p->row_bytes);
+        memset(out, 0, (size_t)nrows * p->row_bytes);
+        for (int i = 0; i < nrows; i++) {
+            HIP_TRY(hipMemcpy(raw.data(), p->d_dec + ((size_t)frame * p->cap_rows + row0 + i) * p->row_bytes, p->row_bytes, hipMemcpyDeviceToHost));
+            const int rot = (row0 + i + 1) % NB;
+            unsigned char *o = out + (size_t)i * p->row_bytes;
+            for (unsigned n = 0; n < p->N; n++) {
+                const unsigned pos = rot == 0 ? n : (((n >> rot) | (n << (NB - rot))) & (p->N - 1));
+                if ((raw[pos >> 3] >> (((pos & 1u) << 2) | ((pos >> 1) & 3u))) & 1u) o[n >> 3] |= (unsigned char)(1u << (n & 7));
+            }
+        }
+        return 0;
+    }
     if (p->variant == VHIP_VARIANT_REGS && p->code == VHIP_KA9Q615) {
         // [row][word][thread] of acs_k15.hip -> natural bitmap
         const int NB = 14;
@@ -501,6 +594,15 @@ int vhip_read_metrics(vhip_decoder *p, int frame, int32_t *out) {
                              ? p->d_metrics + ((size_t)frame * 2 + p->k24_cur[frame]) * p->N
                              : p->d_metrics + (size_t)frame * p->N;
     HIP_TRY(hipMemcpy(tmp.data(), src, (size_t)p->N * sizeof(int16_t), hipMemcpyDeviceToHost));
+    if (p->variant == VHIP_VARIANT_HBM_FUSED) {
+        // the fused K=24 kernels keep the rotating layout between calls: position q holds state rotl^(pos mod 23)(q)
+        const int NB = 23, rot = p->pos % NB;
+        for (unsigned q = 0; q < p->N; q++) {
+            const unsigned st = rot == 0 ? q : (((q << rot) | (q >> (NB - rot))) & (p->N - 1));
+            out[st] = tmp[q];
+        }
+        return 0;
+    }
     for (unsigned i = 0; i < p->N; i++) out[i] = tmp[i];
     return 0;
 }

@@ -67,6 +67,8 @@ def test_hip_reproduces_golden(code):
     variants = [0]
     if int(g["K"]) == 15:
         variants = [1, 2]
+    if int(g["K"]) == 24:
+        variants = [3, 4]
     if int(g["K"]) <= 9:
         variants = [1] + [2 | ((lb + 1) << 8) for lb in ((0, 1, 2) if int(g["K"]) == 7 else (1, 2))]
     for variant in variants:

@@ -7,7 +7,7 @@ import pytest
 
 from common import GPU_CODES, bit_errors, frames, spec_of
 from ka9q_viterbi_comparison_amd import HipViterbi, codes as C
-from ka9q_viterbi_comparison_amd import VARIANT_AUTO, VARIANT_LDS, VARIANT_REGS
+from ka9q_viterbi_comparison_amd import VARIANT_AUTO, VARIANT_HBM, VARIANT_HBM_FUSED, VARIANT_LDS, VARIANT_REGS
 from oracle_lib import OracleDecoder
 
 pytestmark = pytest.mark.gpu
@@ -20,7 +20,7 @@ def regs(lb):
 
 def variants_for(code):
     if code == C.KA9Q224:
-        return [VARIANT_AUTO]
+        return [VARIANT_HBM, VARIANT_HBM_FUSED]
     if code == C.KA9Q615:
         return [VARIANT_LDS, VARIANT_REGS]
     if code in (C.KA9Q27, C.SPIRAL47):
@@ -148,7 +148,8 @@ def test_endstate_start_state_and_ragged_bits(code, variant):
         dec.close()
 
 
-def test_k24_chainback_variants():
+@pytest.mark.parametrize("variant", [VARIANT_HBM, VARIANT_HBM_FUSED])
+def test_k24_chainback_variants(variant):
     """chainback_viterbi224_sse2 has no tail skip: pin both the harness call (nbits) and the
     correct one (nbits+K-1)."""
     code = C.KA9Q224
@@ -156,7 +157,7 @@ def test_k24_chainback_variants():
     B = 8
     steps = B * 8 + spec.K - 1
     payload, syms = frames(code, 3, 1, B, spec.ebn0_db)
-    dec = HipViterbi("224", steps)
+    dec = HipViterbi("224", steps, variant=variant)
     dec.reset()
     dec.update(syms)
     o = OracleDecoder(code, spec.poly, steps)
@@ -188,4 +189,32 @@ def test_k615_forced_renormalisation_and_return_value():
     assert rc == ref["rc"]
     assert np.array_equal(data[0], ref["data"])
     assert np.array_equal(dec.metrics(0), ref["metrics"])
+    dec.close()
+
+
+@pytest.mark.parametrize("variant", [VARIANT_HBM, VARIANT_HBM_FUSED])
+def test_k24_renormalisation_and_incremental(variant):
+    """A K=24 frame long enough to renormalise (viterbi224_sse2.cpp:226-246), fed in ragged pieces so that the
+    speculative replay and the phase bookkeeping of the fused passes are exercised; two frames per handle."""
+    code = C.KA9Q224
+    spec = spec_of(code)
+    B = 56
+    steps = B * 8 + spec.K - 1
+    payload, syms = frames(code, 11, 2, B, spec.ebn0_db)
+    dec = HipViterbi("224", steps, nframes=2, variant=variant)
+    dec.reset()
+    s3 = syms.reshape(2, steps, spec.R)
+    off = 0
+    for n in (3, 30, 100, steps - 133):
+        dec.update(np.ascontiguousarray(s3[:, off:off + n, :]), nbits=n)
+        off += n
+    data, _ = dec.chainback(steps)
+    for f in range(2):
+        ref = oracle_decode(code, syms[f], steps, steps)
+        assert ref["renorms"] >= 1
+        assert np.array_equal(dec.metrics(f), ref["metrics"])
+        assert np.array_equal(data[f], ref["data"])
+        assert bit_errors(data[f][:B], payload[f]) == 0
+        for r in (0, 1, 22, 23, 100, steps - 1):
+            assert np.array_equal(dec.decision_rows(f, r, 1), ref["rows"][r:r + 1]), f"row {r}"
     dec.close()
