@@ -94,6 +94,10 @@ hipError_t launch_k24f_pass(int g, const int16_t *oldm, int16_t *newm, unsigned 
                             int rel_row0, int s_lo, int s_hi, int *flags, hipStream_t stream);
 hipError_t launch_chainback_k24f(const ChainbackRowsArgs &a, hipStream_t stream);
 
+// ---------------------------------------------------------------- chainback_spec.hip (K = 15 / 24, one wave per frame)
+enum { CB_LAY_NATURAL = 0, CB_LAY_K15 = 1, CB_LAY_K24F = 2 };
+hipError_t launch_chainback_spec(int layout, const ChainbackRowsArgs &a, hipStream_t stream);
+
 // ---------------------------------------------------------------- framegen.hip
 hipError_t launch_gen_frames(int K, int R, const int *poly, uint64_t seed, uint64_t frame0, int nframes,
                              int payload_bytes, int amp_q16, int noise_q12, unsigned char *d_payload,

@@ -439,7 +439,8 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
         a.endstate = endstate;
         a.K = p->K;
         a.k224 = 1;
-        HIP_TRY(vh::launch_chainback_k24f(a, p->stream));
+        if (getenv("VHIP_CHAINBACK_SIMPLE")) HIP_TRY(vh::launch_chainback_k24f(a, p->stream));
+        else HIP_TRY(vh::launch_chainback_spec(vh::CB_LAY_K24F, a, p->stream));
         return 0;
     }
     if (p->variant == VHIP_VARIANT_REGS && p->code == VHIP_KA9Q615) {
@@ -454,7 +455,8 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
         a.endstate = endstate;
         a.K = p->K;
         a.k224 = 0;
-        HIP_TRY(vh::launch_chainback_k15(a, p->stream));
+        if (getenv("VHIP_CHAINBACK_SIMPLE")) HIP_TRY(vh::launch_chainback_k15(a, p->stream));
+        else HIP_TRY(vh::launch_chainback_spec(vh::CB_LAY_K15, a, p->stream));
         return 0;
     }
     if (p->variant == VHIP_VARIANT_REGS) {
@@ -483,7 +485,8 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
     a.endstate = endstate;
     a.K = p->K;
     a.k224 = (p->code == VHIP_KA9Q224);
-    HIP_TRY(vh::launch_chainback_rows(a, p->stream));
+    if (p->K >= 15 && !getenv("VHIP_CHAINBACK_SIMPLE")) HIP_TRY(vh::launch_chainback_spec(vh::CB_LAY_NATURAL, a, p->stream));
+    else HIP_TRY(vh::launch_chainback_rows(a, p->stream));
     return 0;
 }
 
