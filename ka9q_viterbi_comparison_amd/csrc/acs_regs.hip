@@ -334,7 +334,7 @@ __device__ __forceinline__ void run_period(u16x2 (&M)[NR_], const unsigned (&cur
 }
 
 template <class C, class P, int LB>
-__global__ __launch_bounds__(256) void acs_regs_kernel(AcsRegsArgs a) {
+__device__ __forceinline__ void acs_regs_body(const AcsRegsArgs &a) {
     using G = RegsCfg<C, P, LB>;
     constexpr int NB = G::NB, R = G::R, NR = G::NR, L = G::L, FPW = G::FPW, DW = G::DW, SW = G::SW;
     const unsigned lane = threadIdx.x & 63u;
@@ -416,11 +416,26 @@ __global__ __launch_bounds__(256) void acs_regs_kernel(AcsRegsArgs a) {
     }
 }
 
+// Two entry points over the same body.  With >= 32 metric registers per lane hipcc's occupancy-driven scheduler
+// serialises the packed ACS chains and pads them with s_nop (303 per period for K=7, L=1); telling it that at most
+// two waves per SIMD will ever be resident lets it interleave independent butterflies instead (0 s_nop).
+template <class C, class P, int LB>
+__global__ __launch_bounds__(256) void acs_regs_kernel(AcsRegsArgs a) {
+    acs_regs_body<C, P, LB>(a);
+}
+template <class C, class P, int LB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void acs_regs_kernel_ilp(AcsRegsArgs a) {
+    acs_regs_body<C, P, LB>(a);
+}
+
 template <class C, class P, int LB>
 static hipError_t launch_regs(const AcsRegsArgs &a, hipStream_t stream) {
     using G = RegsCfg<C, P, LB>;
     const int waves = (a.nframes + G::FPW - 1) / G::FPW;
-    hipLaunchKernelGGL((acs_regs_kernel<C, P, LB>), dim3((waves + 3) / 4), dim3(256), 0, stream, a);
+    if constexpr (G::NR >= 32)
+        hipLaunchKernelGGL((acs_regs_kernel_ilp<C, P, LB>), dim3((waves + 3) / 4), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((acs_regs_kernel<C, P, LB>), dim3((waves + 3) / 4), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
