@@ -1,0 +1,42 @@
+"""The stand-alone C++ harness (harness/viterbi_bench): reference-style flags and JSON schema (src/main.cpp:80-118,
+300-316), decoding on the GPU."""
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "harness", "viterbi_bench")
+REF_KEYS = ["name", "K", "R", "poly", "total_input_bytes", "total_transmit_bits", "total_output_symbols", "sampling_time",
+            "minimum_samples", "total_samples", "init_ns", "update_ns", "chainback_ns", "total_bits", "total_bit_errors",
+            "bit_error_rate"]
+
+
+def test_flag_validation_matches_reference():
+    if not os.path.exists(BIN):
+        pytest.skip("harness not built")
+    r = subprocess.run([BIN, "-t", "-1"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Sampling time must be positive" in r.stderr  # src/main.cpp:344-347
+
+
+@pytest.mark.gpu
+def test_harness_json_schema_and_ber(tmp_path):
+    assert os.path.exists(BIN), "build it: make -C harness"
+    out = tmp_path / "bench.json"
+    r = subprocess.run([BIN, "-t", "0.05", "-n", "2", "-o", str(out), "--frames", "256", "--payload-bytes", "64", "--hard",
+                        "--codes", "27,47,29,49,615"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    entries = json.load(open(out))
+    assert [e["K"] for e in entries] == [7, 7, 9, 9, 15]
+    for e in entries:
+        for k in REF_KEYS:
+            assert k in e, k
+        assert e["name"] == "hip" and e["frames"] == 256
+        assert e["total_samples"] == len(e["update_ns"]) == len(e["chainback_ns"]) == len(e["init_ns"]) >= 3
+        assert e["total_bit_errors"] == 0  # noise-free input decodes without error
+    r = subprocess.run([BIN, "-t", "0.05", "-n", "1", "-o", str(out), "--payload-bytes", "8", "--hard", "--codes", "224"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    e = json.load(open(out))[0]
+    assert e["K"] == 24 and e["total_bit_errors"] == 0  # BER from the nbits+K-1 call
