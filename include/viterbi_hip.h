@@ -32,7 +32,11 @@ enum vhip_code {
     VHIP_KA9Q224 = 3,  /* K=24 r=1/2, ka9q i16 saturating         (viterbi224_sse2.cpp)  */
     VHIP_SPIRAL47 = 4, /* K=7  r=1/4, spiral u8 saturating        (spiral47.cpp)         */
     VHIP_SPIRAL49 = 5, /* K=9  r=1/4, spiral u8 saturating        (spiral49.cpp)         */
-    VHIP_NUM_CODES = 6
+    /* the remaining spiral arithmetic variants (decoder x code matrix of src/main.cpp:363-419) */
+    VHIP_SPIRAL27 = 6, /* K=7  r=1/2, spiral u8 saturating        (spiral27.cpp)         */
+    VHIP_SPIRAL29 = 7, /* K=9  r=1/2, spiral u8 saturating        (spiral29.cpp)         */
+    VHIP_SPIRAL615 = 8,/* K=15 r=1/6, spiral u8 saturating        (spiral615.cpp)        */
+    VHIP_NUM_CODES = 9
 };
 
 typedef struct vhip_decoder vhip_decoder;
@@ -138,6 +142,14 @@ VHIP_DECLARE_FIVE(spiral47_hip, create_spiral47_hip, init_spiral47_hip, update_s
 /* replaces spiral/spiral49.h:5-9 */
 VHIP_DECLARE_FIVE(spiral49_hip, create_spiral49_hip, init_spiral49_hip, update_spiral49_hip,
                   chainback_spiral49_hip, delete_spiral49_hip)
+
+/* replaces spiral/spiral27.h:5-9, spiral29.h, spiral615.h */
+VHIP_DECLARE_FIVE(spiral27_hip, create_spiral27_hip, init_spiral27_hip, update_spiral27_hip,
+                  chainback_spiral27_hip, delete_spiral27_hip)
+VHIP_DECLARE_FIVE(spiral29_hip, create_spiral29_hip, init_spiral29_hip, update_spiral29_hip,
+                  chainback_spiral29_hip, delete_spiral29_hip)
+VHIP_DECLARE_FIVE(spiral615_hip, create_spiral615_hip, init_spiral615_hip, update_spiral615_hip,
+                  chainback_spiral615_hip, delete_spiral615_hip)
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,9 @@ for _t, _c, _i, _u, _cb, _d in [
     ("v224", "create_viterbi224_hip", "init_viterbi224_hip", "update_viterbi224_blk_hip", "chainback_viterbi224_hip", "delete_viterbi224_hip"),
     ("spiral47", "create_spiral47_hip", "init_spiral47_hip", "update_spiral47_hip", "chainback_spiral47_hip", "delete_spiral47_hip"),
     ("spiral49", "create_spiral49_hip", "init_spiral49_hip", "update_spiral49_hip", "chainback_spiral49_hip", "delete_spiral49_hip"),
+    ("spiral27", "create_spiral27_hip", "init_spiral27_hip", "update_spiral27_hip", "chainback_spiral27_hip", "delete_spiral27_hip"),
+    ("spiral29", "create_spiral29_hip", "init_spiral29_hip", "update_spiral29_hip", "chainback_spiral29_hip", "delete_spiral29_hip"),
+    ("spiral615", "create_spiral615_hip", "init_spiral615_hip", "update_spiral615_hip", "chainback_spiral615_hip", "delete_spiral615_hip"),
 ]:
     _FIVE += [
         (_c, C.c_void_p, [_i32p, C.c_int]),

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(THREADS) void acs_lds_kernel(AcsLdsArgs a) {
                 const int n = tid + i * THREADS;
                 const int j = n >> 1;
                 const int t = C::bm(s, cls[i]);
-                const int tc = C::bm_comp - t;
+                const int tc = C::bm_tc(t);
                 const bool odd = n & 1;
                 // new[2j]: m0 = old[j]+t, m1 = old[j+H]+t' ; new[2j+1]: m2 = old[j]+t', m3 = old[j+H]+t
                 const int lower = metric_add<C>(oldm[j], odd ? tc : t);
@@ -161,6 +161,9 @@ hipError_t launch_acs_lds(int code, const AcsLdsArgs &a, hipStream_t stream) {
     case VHIP_KA9Q29: return launch_one<Code29, 256>(a, stream);
     case VHIP_SPIRAL49: return launch_one<Code49, 256>(a, stream);
     case VHIP_KA9Q615: return launch_one<Code615, 1024>(a, stream);
+    case VHIP_SPIRAL27: return launch_one<CodeS27, 64>(a, stream);
+    case VHIP_SPIRAL29: return launch_one<CodeS29, 256>(a, stream);
+    case VHIP_SPIRAL615: return launch_one<CodeS615, 1024>(a, stream);
     }
     return hipErrorInvalidValue;
 }

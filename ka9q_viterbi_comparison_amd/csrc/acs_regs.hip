@@ -142,6 +142,12 @@ __device__ __forceinline__ void branch_fields(const unsigned (&s)[C::R], unsigne
         const unsigned a0[2] = {s[0], x0}, a1[2] = {s[1], x1};
 #pragma unroll
         for (int c = 0; c < 4; c++) T[c] = ((a0[c & 1] + a1[c >> 1] + 1u) >> 5) << 8;
+    } else if constexpr (C::R == 2) {
+        // t = (((a0+a1+1)>>1)>>2)&63                                                  spiral27.cpp:164-169
+        const unsigned x0 = s[0] ^ 255u, x1 = s[1] ^ 255u;
+        const unsigned a0[2] = {s[0], x0}, a1[2] = {s[1], x1};
+#pragma unroll
+        for (int c = 0; c < 4; c++) T[c] = (((a0[c & 1] + a1[c >> 1] + 1u) >> 3) & 63u) << 8;
     } else {
         // t = (sum_r ((a_r>>2)&63)) >> 2; (s^255)>>2 == 63-(s>>2)                     spiral47.cpp:164-219
         unsigned g[4], h[4];
@@ -450,14 +456,16 @@ bool regs_poly_supported(int code, const int *poly) {
     case VHIP_SPIRAL47: return eq(Poly47::v, 4);
     case VHIP_KA9Q29: return eq(Poly29::v, 2);
     case VHIP_SPIRAL49: return eq(Poly49::v, 4);
+    case VHIP_SPIRAL27: return eq(Poly27::v, 2);
+    case VHIP_SPIRAL29: return eq(Poly29::v, 2);
     }
     return false;
 }
 
 bool regs_lanes_supported(int code, int lb) {
     switch (code) {
-    case VHIP_KA9Q27: case VHIP_SPIRAL47: return lb >= 0 && lb <= 2;
-    case VHIP_KA9Q29: case VHIP_SPIRAL49: return lb >= 1 && lb <= 2;
+    case VHIP_KA9Q27: case VHIP_SPIRAL47: case VHIP_SPIRAL27: return lb >= 0 && lb <= 2;
+    case VHIP_KA9Q29: case VHIP_SPIRAL49: case VHIP_SPIRAL29: return lb >= 1 && lb <= 2;
     }
     return false;
 }
@@ -494,6 +502,15 @@ hipError_t launch_acs_regs(int code, int lb, const AcsRegsArgs &a, hipStream_t s
     case VHIP_SPIRAL49:
         if (lb == 1) return launch_regs<Code49, Poly49, 1>(a, stream);
         if (lb == 2) return launch_regs<Code49, Poly49, 2>(a, stream);
+        break;
+    case VHIP_SPIRAL27:
+        if (lb == 0) return launch_regs<CodeS27, Poly27, 0>(a, stream);
+        if (lb == 1) return launch_regs<CodeS27, Poly27, 1>(a, stream);
+        if (lb == 2) return launch_regs<CodeS27, Poly27, 2>(a, stream);
+        break;
+    case VHIP_SPIRAL29:
+        if (lb == 1) return launch_regs<CodeS29, Poly29, 1>(a, stream);
+        if (lb == 2) return launch_regs<CodeS29, Poly29, 2>(a, stream);
         break;
     }
     return hipErrorInvalidValue;

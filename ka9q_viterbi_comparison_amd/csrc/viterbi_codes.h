@@ -34,6 +34,7 @@ struct Ka9qU8Mod {
         int a0 = s[0] ^ ((c & 1u) ? 255 : 0), a1 = s[1] ^ ((c & 2u) ? 255 : 0);
         return ((a0 + a1 + 1) >> 1) >> 4;
     }
+    static VH_HD int bm_tc(int t) { return 15 - t; }  // m_metric = 15 - metric          viterbi27_sse2.cpp:146
 };
 
 // ka9q K=15 r=1/6: viterbi615_sse2.cpp:33-39, :132-148 (sum of six, adds_epi16, min + cmpeq),
@@ -53,6 +54,7 @@ struct Ka9q615 {
         for (int r = 0; r < 6; r++) t += s[r] ^ (((c >> r) & 1u) ? 255 : 0);
         return t;
     }
+    static VH_HD int bm_tc(int t) { return 1530 - t; }
 };
 
 // ka9q K=24 r=1/2: viterbi224_sse2.cpp:39-45, :159-194 (cmpgt before min: tie -> lower), renorm >= 25000 (:226).
@@ -68,6 +70,7 @@ struct Ka9q224 {
     static VH_HD int bm(const int *s, unsigned c) {
         return (s[0] ^ ((c & 1u) ? 255 : 0)) + (s[1] ^ ((c & 2u) ? 255 : 0));
     }
+    static VH_HD int bm_tc(int t) { return 510 - t; }
 };
 
 // spiral K=7/9 r=1/4: spiral47.cpp:54-61, :164-227 (6-bit terms, adds_epu8, min_epu8 + cmpeq: tie -> upper),
@@ -88,6 +91,47 @@ struct SpiralR4 {
         for (int r = 0; r < 4; r++) q += ((s[r] ^ (((c >> r) & 1u) ? 255 : 0)) >> 2) & 63;  // <= 252: never saturates
         return (q >> 2) & 63;
     }
+    static VH_HD int bm_tc(int t) { return 63 - t; }
+};
+
+// spiral K=7/9 r=1/2: spiral27.cpp:164-173 (avg_epu8, >>2, &63), renormalise when new[0] > 210 (spiral27.cpp:236,
+// spiral29.cpp:507); otherwise as SpiralR4.
+template <int K_>
+struct SpiralR2 {
+    static constexpr int K = K_, R = 2;
+    static constexpr Metric metric = U8SAT;
+    static constexpr int init_all = 63, init_start = 0;
+    static constexpr int bm_comp = 63;
+    static constexpr bool tie_upper = true;
+    static constexpr bool renorm = true;
+    static constexpr int renorm_thr = 210;
+    static constexpr bool incremental = false;
+    static VH_HD int bm(const int *s, unsigned c) {
+        int a0 = s[0] ^ ((c & 1u) ? 255 : 0), a1 = s[1] ^ ((c & 2u) ? 255 : 0);
+        return (((a0 + a1 + 1) >> 1) >> 2) & 63;
+    }
+    static VH_HD int bm_tc(int t) { return 63 - t; }
+};
+
+// spiral K=15 r=1/6: spiral615.cpp:149-242 (six 6-bit terms through adds_epu8: the sum saturates at 255; >>2, &63),
+// t' = subs_epu8(94, t) (clamps at 0), scalar renormalize(.., 74) (spiral615.cpp:31-40,269,408).
+struct Spiral615 {
+    static constexpr int K = 15, R = 6;
+    static constexpr Metric metric = U8SAT;
+    static constexpr int init_all = 63, init_start = 0;
+    static constexpr int bm_comp = 94;
+    static constexpr bool tie_upper = true;
+    static constexpr bool renorm = true;
+    static constexpr int renorm_thr = 74;
+    static constexpr bool incremental = false;
+    static VH_HD int bm(const int *s, unsigned c) {
+        int q = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++) q += ((s[r] ^ (((c >> r) & 1u) ? 255 : 0)) >> 2) & 63;
+        q = q > 255 ? 255 : q;  // every partial sum of adds_epu8 saturates; the terms are non-negative
+        return (q >> 2) & 63;
+    }
+    static VH_HD int bm_tc(int t) { return 94 - t < 0 ? 0 : 94 - t; }
 };
 
 using Code27 = Ka9qU8Mod<7>;
@@ -96,6 +140,9 @@ using Code615 = Ka9q615;
 using Code224 = Ka9q224;
 using Code47 = SpiralR4<7, 126>;
 using Code49 = SpiralR4<9, 103>;
+using CodeS27 = SpiralR2<7>;
+using CodeS29 = SpiralR2<9>;
+using CodeS615 = Spiral615;
 
 struct CodeInfo {
     int K, R;
@@ -109,6 +156,9 @@ static inline CodeInfo code_info(int code) {
     case VHIP_KA9Q224: return {24, 2, 1};
     case VHIP_SPIRAL47: return {7, 4, 0};
     case VHIP_SPIRAL49: return {9, 4, 0};
+    case VHIP_SPIRAL27: return {7, 2, 0};
+    case VHIP_SPIRAL29: return {9, 2, 0};
+    case VHIP_SPIRAL615: return {15, 6, 0};
     }
     return {0, 0, 0};
 }

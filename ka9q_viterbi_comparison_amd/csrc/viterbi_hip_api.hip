@@ -82,6 +82,7 @@ int init_all_of(int code) {
     case VHIP_KA9Q224: return vh::Code224::init_all;
     case VHIP_SPIRAL47: return vh::Code47::init_all;
     case VHIP_SPIRAL49: return vh::Code49::init_all;
+    case VHIP_SPIRAL27: case VHIP_SPIRAL29: case VHIP_SPIRAL615: return 63;
     }
     return 0;
 }
@@ -673,5 +674,11 @@ VHIP_DEFINE_FIVE(spiral47_hip, VHIP_SPIRAL47, create_spiral47_hip, init_spiral47
                  chainback_spiral47_hip, delete_spiral47_hip)
 VHIP_DEFINE_FIVE(spiral49_hip, VHIP_SPIRAL49, create_spiral49_hip, init_spiral49_hip, update_spiral49_hip,
                  chainback_spiral49_hip, delete_spiral49_hip)
+VHIP_DEFINE_FIVE(spiral27_hip, VHIP_SPIRAL27, create_spiral27_hip, init_spiral27_hip, update_spiral27_hip,
+                 chainback_spiral27_hip, delete_spiral27_hip)
+VHIP_DEFINE_FIVE(spiral29_hip, VHIP_SPIRAL29, create_spiral29_hip, init_spiral29_hip, update_spiral29_hip,
+                 chainback_spiral29_hip, delete_spiral29_hip)
+VHIP_DEFINE_FIVE(spiral615_hip, VHIP_SPIRAL615, create_spiral615_hip, init_spiral615_hip, update_spiral615_hip,
+                 chainback_spiral615_hip, delete_spiral615_hip)
 
 }  // extern "C"

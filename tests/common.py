@@ -12,11 +12,11 @@ ORACLE_CODES = {
     C.KA9Q224: ("224", C.CODES["224"]),
     C.SPIRAL47: ("47", C.CODES["47"]),
     C.SPIRAL49: ("49", C.CODES["49"]),
-    C.SPIRAL27: ("27", C.CODES["27"]),
-    C.SPIRAL29: ("29", C.CODES["29"]),
-    C.SPIRAL615: ("615", C.CODES["615"]),
+    C.SPIRAL27: ("spiral27", C.CODES["spiral27"]),
+    C.SPIRAL29: ("spiral29", C.CODES["spiral29"]),
+    C.SPIRAL615: ("spiral615", C.CODES["spiral615"]),
 }
-GPU_CODES = [C.KA9Q27, C.KA9Q29, C.KA9Q615, C.KA9Q224, C.SPIRAL47, C.SPIRAL49]
+GPU_CODES = [C.KA9Q27, C.KA9Q29, C.KA9Q615, C.KA9Q224, C.SPIRAL47, C.SPIRAL49, C.SPIRAL27, C.SPIRAL29, C.SPIRAL615]
 
 
 def spec_of(code):

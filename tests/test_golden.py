@@ -12,7 +12,8 @@ from oracle_lib import OracleDecoder
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 NAMES = {C.KA9Q27: "ka9q27", C.KA9Q29: "ka9q29", C.KA9Q615: "ka9q615", C.KA9Q224: "ka9q224", C.SPIRAL47: "spiral47",
          C.SPIRAL49: "spiral49", C.SPIRAL27: "spiral27", C.SPIRAL29: "spiral29", C.SPIRAL615: "spiral615"}
-HIP_NAMES = {C.KA9Q27: "27", C.KA9Q29: "29", C.KA9Q615: "615", C.KA9Q224: "224", C.SPIRAL47: "47", C.SPIRAL49: "49"}
+HIP_NAMES = {C.KA9Q27: "27", C.KA9Q29: "29", C.KA9Q615: "615", C.KA9Q224: "224", C.SPIRAL47: "47", C.SPIRAL49: "49",
+             C.SPIRAL27: "spiral27", C.SPIRAL29: "spiral29", C.SPIRAL615: "spiral615"}
 
 
 def sha(a):
@@ -66,7 +67,7 @@ def test_hip_reproduces_golden(code):
     steps, nrows, B = int(g["steps"]), int(g["nrows"]), int(g["payload_bytes"])
     variants = [0]
     if int(g["K"]) == 15:
-        variants = [1, 2]
+        variants = [1, 2] if code == C.KA9Q615 else [1]
     if int(g["K"]) == 24:
         variants = [3, 4]
     if int(g["K"]) <= 9:

@@ -23,7 +23,9 @@ def variants_for(code):
         return [VARIANT_HBM, VARIANT_HBM_FUSED]
     if code == C.KA9Q615:
         return [VARIANT_LDS, VARIANT_REGS]
-    if code in (C.KA9Q27, C.SPIRAL47):
+    if code == C.SPIRAL615:
+        return [VARIANT_LDS]
+    if code in (C.KA9Q27, C.SPIRAL47, C.SPIRAL27):
         return [VARIANT_LDS, regs(0), regs(1), regs(2)]
     return [VARIANT_LDS, regs(1), regs(2)]
 
@@ -57,7 +59,9 @@ def test_batch_matches_oracle(code, variant, ebn0):
     """A batch of frames: every decision row, final metric, decoded byte and return code equals the oracle's."""
     spec = spec_of(code)
     B = 8 if spec.K == 24 else (24 if spec.K == 15 else 40)
-    nframes = 1 if spec.K == 24 else (3 if spec.K == 15 else 70)  # 70: more than one wave of frames, ragged
+    nframes = 1 if spec.K == 24 else (3 if spec.K == 15 else 70)
+    if code == C.SPIRAL615:
+        B = 25  # odd step count is dropped by spiral; keep steps even: 25*8+14  # 70: more than one wave of frames, ragged
     steps = B * 8 + spec.K - 1
     payload, syms = frames(code, 77 + code, nframes, B, None if ebn0 == "hard" else spec.ebn0_db)
     dec = HipViterbi(spec.name, steps, nframes=nframes, variant=variant)
@@ -103,7 +107,7 @@ def test_incremental_update(code, variant):
     dec.close()
 
 
-@pytest.mark.parametrize("code,variant", [c for c in CASES if c[0] in (C.SPIRAL47, C.SPIRAL49)])
+@pytest.mark.parametrize("code,variant", [c for c in CASES if c[0] in (C.SPIRAL47, C.SPIRAL49, C.SPIRAL27, C.SPIRAL29, C.SPIRAL615)])
 def test_spiral_restart_and_odd_step(code, variant):
     """spiral update restarts at row 0 on every call and drops an odd last step (spiral47.cpp:536-538)."""
     spec = spec_of(code)
