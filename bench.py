@@ -94,11 +94,11 @@ def cpu_baseline(spec, payload_bits, budget_s=12.0):
     for d in decs:
         d.close()
     return {
-        "value": round(multi, 3),
+        "value": round(multi, 6),
         "unit": "Msymbols/s",
         "cores": cores,
         "kind": "reference" if use_ref else "port",
-        "single_thread_value": round(single, 3),
+        "single_thread_value": round(single, 6),
         "sample": f"{n1} (1 thread) + {nall} ({cores} threads) one-frame decodes (reset+update+chainback) of K={spec.K} "
                   f"r=1/{spec.R} x {payload_bits} bits, AWGN Eb/N0={spec.ebn0_db} dB, {budget_s:.0f} s budget",
     }
@@ -135,10 +135,10 @@ def main():
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
     spec = C.CODES[args.code]
-    defaults = {"27": (65536, 2048), "47": (65536, 2048), "29": (32768, 2048), "49": (32768, 2048),
-                "615": (4096, 2048), "224": (1, 2048)}
-    frames = args.frames or defaults[args.code][0]
-    payload_bits = args.payload_bits or defaults[args.code][1]
+    # BASELINE.json configs: K=7 x 65536 frames, K=15 x 4096 frames, K=24 single long frame; K=9 sized in between
+    defaults = {7: (65536, 2048), 9: (32768, 2048), 15: (4096, 2048), 24: (1, 2048)}
+    frames = args.frames or defaults[spec.K][0]
+    payload_bits = args.payload_bits or defaults[spec.K][1]
     payload_bytes = payload_bits // 8
     nsteps = payload_bits + spec.K - 1
     ebn0 = spec.ebn0_db if args.ebn0 is None else args.ebn0
@@ -206,7 +206,7 @@ def main():
                 traffic = None
         out = {
             "metric": f"Msymbols/s decoded, K={spec.K} r=1/{spec.R} (init + ACS update + chainback)",
-            "value": round(value, 3),
+            "value": round(value, 6),
             "unit": "Msymbols/s",
             "n_gpus": n_gpus,
             "steps": args.steps,
@@ -221,7 +221,7 @@ def main():
                                    f"({nsteps} trellis steps, {nsteps * spec.R} symbols/frame)",
                        "frames_per_gpu": frames, "payload_bits": payload_bits, "variant": dec.variant,
                        "parallelism": f"frame-shard x{n_gpus}, no collective"},
-            "update_msym_s": round(frames * nsteps * spec.R * n_gpus / (upd_ms * 1e-3) / 1e6, 3),
+            "update_msym_s": round(frames * nsteps * spec.R * n_gpus / (upd_ms * 1e-3) / 1e6, 6),
             "chainback_mbit_s": round(frames * cb_bits * n_gpus / (cb_ms * 1e-3) / 1e6, 3),
             "update_ms": round(upd_ms, 4),
             "chainback_ms": round(cb_ms, 4),
