@@ -203,11 +203,12 @@ struct RegsStep {
             // ---- register-bit stage: partner lives in another register of the same lane
             constexpr int rb = b - (LB + 1);
             constexpr unsigned ch = cls_c<P, R>(rotl_c<NB>(1u << LB, PHI));
-            unsigned TP[NC], TQ[NC];
+            unsigned TP[NC], TQ[NC], TE[NC];
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 TP[c] = T[c] | (T[c ^ ch] << 16);
                 TQ[c] = COMP2 - TP[c];
+                TE[c] = as_u32(as_v(TP[c]) - as_v(TQ[c]));  // t - t' per field (mod 2^16)
             }
             static_for<NR / 2>([&](auto I) {
                 constexpr int i = decltype(I)::value;
@@ -216,9 +217,25 @@ struct RegsStep {
                 constexpr unsigned cr = cls_c<P, R>(rotl_c<NB>((unsigned)r0 << (LB + 1), PHI));
                 const u16x2 A = M[r0], B = M[r1];
                 const u16x2 t = as_v(TP[cr]), tc = as_v(TQ[cr]);
-                const u16x2 m0 = madd<SAT>(A, t), m1 = madd<SAT>(B, tc), m2 = madd<SAT>(A, tc), m3 = madd<SAT>(B, t);
-                M[r0] = acs_pk<SAT, (r0 & 7) + 1>(m0, m1, acc[r0 >> 3]);
-                M[r1] = acs_pk<SAT, (r1 & 7) + 1>(m2, m3, acc[r1 >> 3]);
+                if constexpr (SAT) {
+                    const u16x2 m0 = madd<SAT>(A, t), m1 = madd<SAT>(B, tc), m2 = madd<SAT>(A, tc), m3 = madd<SAT>(B, t);
+                    M[r0] = acs_pk<SAT, (r0 & 7) + 1>(m0, m1, acc[r0 >> 3]);
+                    M[r1] = acs_pk<SAT, (r1 & 7) + 1>(m2, m3, acc[r1 >> 3]);
+                } else {
+                    // modular family: everything is exact mod 2^16, so the two differences share A-B:
+                    //   m0-m1 = (A-B) + (t-t'),  m2-m3 = (A-B) - (t-t')      (9 packed ops per butterfly pair instead of 10)
+                    const u16x2 e = as_v(TE[cr]);
+                    const u16x2 dab = A - B;
+                    const i16x2 zero = {0, 0};
+                    const u16x2 p0 = (u16x2)__builtin_elementwise_max((i16x2)(dab + e), zero);
+                    const u16x2 p1 = (u16x2)__builtin_elementwise_max((i16x2)(dab - e), zero);
+                    const u16x2 k0 = {(unsigned short)(1u << ((r0 & 7) + 1)), (unsigned short)(1u << ((r0 & 7) + 1))};
+                    const u16x2 k1 = {(unsigned short)(1u << ((r1 & 7) + 1)), (unsigned short)(1u << ((r1 & 7) + 1))};
+                    acc[r0 >> 3] |= as_u32(__builtin_elementwise_min(p0, k0));
+                    acc[r1 >> 3] |= as_u32(__builtin_elementwise_min(p1, k1));
+                    M[r0] = (A + t) - p0;   // survivor = decision ? upper : lower = lower - positive part
+                    M[r1] = (A + tc) - p1;
+                }
             });
         } else if constexpr (b == LB) {
             // ---- half stage: old[j] is the low field, old[j+H] the high field of the same register

@@ -108,10 +108,12 @@ int ensure_stage(unsigned char **buf, size_t *cap, size_t need, size_t *total) {
     return 0;
 }
 
-// lanes per frame for the REGS kernels: the smallest L that still gives >= 2 waves per SIMD on 256 CUs x 4 SIMDs
+// lanes per frame for the REGS kernels: the smallest L that still puts a wave on (most of) the 1024 SIMDs.  Fewer
+// lanes per frame means fewer duplicated branch-metric instructions and fewer half/lane stages; measured on 65536
+// K=7 frames: L=1 0.92 ms, L=2 1.10 ms, L=4 1.31 ms.
 int auto_regs_lb(int code, int nframes) {
     int lb = 0;
-    while (lb < 2 && (long)nframes * (1 << lb) < 64L * 2048) lb++;
+    while (lb < 2 && (long)nframes * (1 << lb) < 64L * 768) lb++;
     while (!vh::regs_lanes_supported(code, lb) && lb < 2) lb++;
     if (const char *e = getenv("VHIP_REGS_LB")) {
         const int v = atoi(e);
