@@ -1,0 +1,109 @@
+"""BASELINE.json's full-size configurations on the GPU, checked through size-independent properties:
+encode -> (noise-free) channel -> decode round trip with zero bit errors, agreement between independent kernel
+families on the whole batch (a checksum over every decoded byte), and exact agreement with the CPU oracle on
+sampled frames.  The oracle cannot decode 65536 frames in seconds; the properties can be checked on all of them."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from common import spec_of
+from ka9q_viterbi_comparison_amd import HipViterbi, codes as C, count_bit_errors_dev, gen_frames_dev, noise_q12
+from ka9q_viterbi_comparison_amd import VARIANT_HBM, VARIANT_HBM_FUSED, VARIANT_LDS, VARIANT_REGS
+from oracle_lib import OracleDecoder
+
+pytestmark = pytest.mark.gpu
+
+
+def decode_batch(name, frames, payload_bits, hard, variant=0, seed=0x5EED, cb_bits=None):
+    spec = C.CODES[name]
+    B = payload_bits // 8
+    steps = payload_bits + spec.K - 1
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    d_payload = torch.empty(frames * B, dtype=torch.uint8, device=dev)
+    d_syms = torch.empty(frames * steps * spec.R, dtype=torch.uint8, device=dev)
+    if hard:
+        gen_frames_dev(spec, seed, 0, frames, B, C.HARD_AMP_Q16, 0, d_payload, d_syms, stream)
+    else:
+        gen_frames_dev(spec, seed, 0, frames, B, C.SOFT_AMP_Q16, noise_q12(spec.R, C.SOFT_AMP, spec.ebn0_db), d_payload, d_syms, stream)
+    cb_bits = cb_bits or payload_bits
+    d_out = torch.zeros(frames * ((cb_bits + 7) // 8), dtype=torch.uint8, device=dev)
+    dec = HipViterbi(name, steps, nframes=frames, variant=variant, stream=stream)
+    dec.reset()
+    dec.update(d_syms, nbits=steps)
+    dec.chainback(cb_bits, out=d_out)
+    torch.cuda.synchronize()
+    dec.close()
+    return spec, d_payload, d_syms, d_out
+
+
+def oracle_frame(spec, syms, steps, nbits):
+    o = OracleDecoder(spec.code, spec.poly, steps)
+    o.update(syms, steps)
+    data, _ = o.chainback(nbits)
+    o.close()
+    return data
+
+
+def test_config2_k7_65536_frames_roundtrip_and_cross_kernel():
+    """configs[1]: K=7 r=1/2, 65536 frames x 2048 bits."""
+    frames, bits = 65536, 2048
+    spec, d_payload, d_syms, d_out = decode_batch("27", frames, bits, hard=True)
+    assert count_bit_errors_dev(d_out, d_payload, frames * bits // 8) == 0
+    # AWGN: the register kernels (L=1 and L=2) and the LDS kernel agree on every decoded byte of the batch
+    sums = []
+    for variant in (VARIANT_REGS | (1 << 8), VARIANT_REGS | (2 << 8), VARIANT_LDS):
+        spec, d_payload, d_syms, d_out = decode_batch("27", frames, bits, hard=False, variant=variant)
+        sums.append(zlib.crc32(d_out.cpu().numpy().tobytes()))
+    assert len(set(sums)) == 1
+    # ... and sampled frames equal the CPU oracle exactly
+    steps = bits + spec.K - 1
+    out = d_out.cpu().numpy().reshape(frames, bits // 8)
+    syms = d_syms.cpu().numpy().reshape(frames, steps * spec.R)
+    for f in (0, 1, 4095, 32767, 40000, 65535):
+        assert np.array_equal(out[f], oracle_frame(spec, syms[f], steps, bits)), f
+    errs = count_bit_errors_dev(d_out, d_payload, frames * bits // 8)
+    assert 0 < errs < frames * bits * 1e-3  # Eb/N0 = 4 dB: a few errors per million bits, not a broken decoder
+
+
+def test_config3_k15_4096_frames():
+    """configs[2]: K=15 r=1/6, 4096 frames x 2048 bits (17 GB of decision history resident in HBM)."""
+    frames, bits = 4096, 2048
+    spec, d_payload, d_syms, d_out = decode_batch("615", frames, bits, hard=True)
+    assert count_bit_errors_dev(d_out, d_payload, frames * bits // 8) == 0
+    spec, d_payload, d_syms, d_out = decode_batch("615", frames, bits, hard=False)
+    steps = bits + spec.K - 1
+    out = d_out.cpu().numpy().reshape(frames, bits // 8)
+    for f in (0, 2047, 4095):
+        s = d_syms[f * steps * spec.R:(f + 1) * steps * spec.R].cpu().numpy()
+        assert np.array_equal(out[f], oracle_frame(spec, s, steps, bits)), f
+
+
+@pytest.mark.parametrize("bits", [2048, 16384])
+def test_config4_k24_long_frame(bits):
+    """configs[3]: K=24 single long frame.  Round trip through the correct chainback convention (nbits+K-1,
+    SURVEY.md §0.4), and the per-step and fused kernel families agree on every decoded byte (AWGN input)."""
+    spec = C.CODES["224"]
+    steps = bits + spec.K - 1
+    spec, d_payload, d_syms, d_out = decode_batch("224", 1, bits, hard=True, cb_bits=steps)
+    assert count_bit_errors_dev(d_out, d_payload, bits // 8) == 0
+    outs = []
+    for variant in (VARIANT_HBM, VARIANT_HBM_FUSED):
+        spec, d_payload, d_syms, d_out = decode_batch("224", 1, bits, hard=False, variant=variant, cb_bits=steps)
+        outs.append(d_out.cpu().numpy().copy())
+        assert count_bit_errors_dev(d_out, d_payload, bits // 8) == 0  # K=24 at 4 dB: error free
+    assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("name,frames", [("47", 65536), ("29", 32768), ("49", 32768)])
+def test_sweep_codes_roundtrip(name, frames):
+    bits = 2048
+    spec, d_payload, d_syms, d_out = decode_batch(name, frames, bits, hard=True)
+    assert count_bit_errors_dev(d_out, d_payload, frames * bits // 8) == 0
+    sums = []
+    for variant in (VARIANT_REGS, VARIANT_LDS):
+        spec, d_payload, d_syms, d_out = decode_batch(name, frames, bits, hard=False, variant=variant)
+        sums.append(zlib.crc32(d_out.cpu().numpy().tobytes()))
+    assert sums[0] == sums[1]
