@@ -155,13 +155,38 @@ __global__ __launch_bounds__(256) void acs_k24f_pass_kernel(const int16_t *__res
         pt = u << 7;
     }
     i16x2 M[NR];
+    // Group 4 holds 16 CONTIGUOUS vectors per thread (256 B), so a direct load would touch 64 separate 256-byte
+    // chunks per wave instruction.  Instead each wave streams its 16 KiB tile in lane-linear order (1 KiB per
+    // instruction) and transposes it through a wave-private, XOR-swizzled LDS tile (conflict-free both ways).
+    __shared__ uint4 tile[G == 4 ? 4 * 1024 : 1];
+    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    if constexpr (G == 4) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(oldm) + (size_t)(u - lane) * 16;  // wave tile: 1024 vectors
+        uint4 *tw = tile + wv * 1024;
 #pragma unroll
-    for (int v = 0; v < 16; v++) {
-        const uint4 q = *reinterpret_cast<const uint4 *>(oldm + (pt | ((unsigned)v << BS)));
-        M[4 * v] = as_v(q.x);
-        M[4 * v + 1] = as_v(q.y);
-        M[4 * v + 2] = as_v(q.z);
-        M[4 * v + 3] = as_v(q.w);
+        for (int i = 0; i < 16; i++) {
+            const unsigned gv = i * 64 + lane;  // vector index inside the tile: thread gv>>4, slot gv&15
+            tw[(gv & ~15u) | ((gv ^ (gv >> 4)) & 15u)] = src[gv];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            const uint4 q = tw[lane * 16 + ((v ^ lane) & 15u)];
+            M[4 * v] = as_v(q.x);
+            M[4 * v + 1] = as_v(q.y);
+            M[4 * v + 2] = as_v(q.z);
+            M[4 * v + 3] = as_v(q.w);
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(oldm + (pt | ((unsigned)v << BS)));
+            M[4 * v] = as_v(q.x);
+            M[4 * v + 1] = as_v(q.y);
+            M[4 * v + 2] = as_v(q.z);
+            M[4 * v + 3] = as_v(q.w);
+        }
     }
     sfor<NP>([&](auto I) {
         constexpr int S = decltype(I)::value;
@@ -188,10 +213,24 @@ __global__ __launch_bounds__(256) void acs_k24f_pass_kernel(const int16_t *__res
             }
         }
     });
+    if constexpr (G == 4) {
+        uint4 *tw = tile + wv * 1024;
 #pragma unroll
-    for (int v = 0; v < 16; v++)
-        *reinterpret_cast<uint4 *>(newm + (pt | ((unsigned)v << BS))) =
-            make_uint4(as_u32(M[4 * v]), as_u32(M[4 * v + 1]), as_u32(M[4 * v + 2]), as_u32(M[4 * v + 3]));
+        for (int v = 0; v < 16; v++)
+            tw[lane * 16 + ((v ^ lane) & 15u)] = make_uint4(as_u32(M[4 * v]), as_u32(M[4 * v + 1]), as_u32(M[4 * v + 2]), as_u32(M[4 * v + 3]));
+        __syncthreads();
+        uint4 *dst = reinterpret_cast<uint4 *>(newm) + (size_t)(u - lane) * 16;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const unsigned gv = i * 64 + lane;
+            dst[gv] = tw[(gv & ~15u) | ((gv ^ (gv >> 4)) & 15u)];
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < 16; v++)
+            *reinterpret_cast<uint4 *>(newm + (pt | ((unsigned)v << BS))) =
+                make_uint4(as_u32(M[4 * v]), as_u32(M[4 * v + 1]), as_u32(M[4 * v + 2]), as_u32(M[4 * v + 3]));
+    }
 }
 
 // chainback over position-bitmap rows; same walk as chainback_viterbi224_sse2 (viterbi224_sse2.cpp:79-121): no tail

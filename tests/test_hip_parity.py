@@ -222,3 +222,62 @@ def test_k24_renormalisation_and_incremental(variant):
         for r in (0, 1, 22, 23, 100, steps - 1):
             assert np.array_equal(dec.decision_rows(f, r, 1), ref["rows"][r:r + 1]), f"row {r}"
     dec.close()
+
+
+def spec_is_incremental(code):
+    return code in (C.KA9Q27, C.KA9Q29, C.KA9Q615, C.KA9Q224)
+
+
+@pytest.mark.parametrize("code,variant", [c for c in CASES if c[0] != C.KA9Q224])
+def test_adversarial_symbols(code, variant):
+    """Saturation / wrap-around corner cases: all-0, all-255, erasure-like mid-scale symbols, alternating extremes,
+    ramps and uniform noise -- one pattern per frame of a batch, every row / metric / byte against the oracle."""
+    spec = spec_of(code)
+    B = 16 if spec.K < 15 else 10
+    steps = B * 8 + spec.K - 1
+    if not spec_is_incremental(code):
+        steps -= steps % 2
+    n = steps * spec.R
+    rng = np.random.default_rng(99)
+    pats = np.stack([
+        np.zeros(n, np.uint8), np.full(n, 255, np.uint8), np.full(n, 128, np.uint8), np.full(n, 127, np.uint8),
+        np.tile(np.array([0, 255], np.uint8), n)[:n], (np.arange(n) % 256).astype(np.uint8),
+        rng.integers(0, 256, n, dtype=np.uint8), rng.choice(np.array([0, 255], np.uint8), n),
+        rng.choice(np.array([0, 127, 128, 255], np.uint8), n),
+    ])
+    dec = HipViterbi(spec.name, steps, nframes=len(pats), variant=variant)
+    dec.reset()
+    dec.update(pats, nbits=steps)
+    nb = (B * 8) - 5
+    data, _ = dec.chainback(nb)
+    for f in range(len(pats)):
+        ref = oracle_decode(code, pats[f], steps, nb)
+        assert np.array_equal(dec.decision_rows(f, 0, steps), ref["rows"]), f"rows, pattern {f}"
+        assert np.array_equal(dec.metrics(f), ref["metrics"]), f"metrics, pattern {f}"
+        assert np.array_equal(data[f], ref["data"]), f"bytes, pattern {f}"
+    dec.close()
+
+
+@pytest.mark.parametrize("code", GPU_CODES)
+def test_empty_and_degenerate_calls(code):
+    """Zero-length update / chainback are no-ops; chainback before any update reads all-zero rows like the oracle;
+    more steps than the handle was created for is an error, not a buffer overrun."""
+    from ka9q_viterbi_comparison_amd._lib import VhipError
+
+    spec = spec_of(code)
+    steps = 40 + spec.K - 1 if spec.K < 24 else 30
+    dec = HipViterbi(spec.name, steps, nframes=2)
+    dec.reset()
+    dec.update(np.zeros((2, 0), np.uint8), nbits=0)
+    assert dec.rows_written == 0
+    data, rc = dec.chainback(0)
+    assert data.shape == (2, 0)
+    data, _ = dec.chainback(16, endstate=5)
+    o = OracleDecoder(code, spec.poly, steps)
+    ref, _ = o.chainback(16, 5)
+    o.close()
+    assert np.array_equal(data[0], ref) and np.array_equal(data[1], ref)
+    too_many = steps + spec.K + 1
+    with pytest.raises(VhipError):
+        dec.update(np.zeros((2, too_many * spec.R), np.uint8), nbits=too_many)
+    dec.close()
