@@ -281,3 +281,38 @@ def test_empty_and_degenerate_calls(code):
     with pytest.raises(VhipError):
         dec.update(np.zeros((2, too_many * spec.R), np.uint8), nbits=too_many)
     dec.close()
+
+
+def test_two_handles_two_streams_and_reuse():
+    """Distinct handles are independent (SURVEY.md §8b threading): two decoders on two streams, interleaved calls,
+    each reused for a second batch after reset(); device-pointer API throughout."""
+    import torch
+
+    code = C.KA9Q27
+    spec = spec_of(code)
+    B, nframes = 24, 200
+    steps = B * 8 + spec.K - 1
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    d1 = HipViterbi("27", steps, nframes=nframes, stream=s1.cuda_stream)
+    d2 = HipViterbi("47", steps, nframes=nframes, stream=s2.cuda_stream)
+    for rnd in range(2):
+        p1, y1 = frames(C.KA9Q27, 100 + rnd, nframes, B, 4.0)
+        p2, y2 = frames(C.SPIRAL47, 200 + rnd, nframes, B, 2.0)
+        t1, t2 = torch.from_numpy(y1).cuda(), torch.from_numpy(y2).cuda()
+        o1 = torch.zeros(nframes * B, dtype=torch.uint8, device="cuda")
+        o2 = torch.zeros(nframes * B, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        d1.reset()
+        d2.reset()
+        d1.update(t1, nbits=steps)
+        d2.update(t2, nbits=steps)
+        d2.chainback(B * 8, out=o2)
+        d1.chainback(B * 8, out=o1)
+        d1.sync()
+        d2.sync()
+        r1, r2 = o1.cpu().numpy().reshape(nframes, B), o2.cpu().numpy().reshape(nframes, B)
+        for f in (0, 63, 64, 199):
+            assert np.array_equal(r1[f], oracle_decode(C.KA9Q27, y1[f], steps, B * 8)["data"])
+            assert np.array_equal(r2[f], oracle_decode(C.SPIRAL47, y2[f], steps, B * 8)["data"])
+    d1.close()
+    d2.close()
