@@ -13,13 +13,19 @@
 // in every phase) raises flags[PENDING] = row+1 when new[0] >= 25000, later passes return at once, and the host
 // replays the raising pass up to that row, renormalises, and continues.
 //
-// Decision row r is a bitmap by POSITION: byte p>>3, bit ((p&1)<<2)|((p>>1)&3); the decision of new state n at row r
-// is at p = rotr^((r+1) mod 23)(n)  (chainback_k24f_kernel below).
+// The 4-step passes keep only 64 positions per thread (16 strided 8-byte vectors, 32 packed VGPRs) so that the chip
+// holds two waves per SIMD and one wave's loads/stores overlap another's arithmetic (two concurrent decodes ran
+// 1.47x faster than two serial ones with 128 positions per thread -- tools/k24_overlap_probe.py).
+//
+// Decision row r (1 MiB) is stored as the kernels produce it: [thread u of the pass][accumulator words], 32 bits per
+// 16 registers (bit (rho & 15) + 16*half).  k24f_locate() in k24f_layout.h maps a position to (word, bit); the decision
+// of new state n at row r is at position rotr^((r+1) mod 23)(n).
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
 #include <utility>
 
+#include "k24f_layout.h"
 #include "kernels.h"
 #include "viterbi_codes.h"
 
@@ -31,7 +37,6 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int K = 24, NB = 23;
 constexpr unsigned N = 1u << NB;
-constexpr int NR = 64;
 constexpr int POLY[2] = {062650457, 062650455};  // src/main.cpp:415
 
 template <class F, int... Is>
@@ -60,10 +65,12 @@ constexpr unsigned cls(unsigned j) {  // bit r = parity((2j) & poly[r])         
 __device__ __forceinline__ unsigned as_u32(i16x2 x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ i16x2 as_v(unsigned x) { return __builtin_bit_cast(i16x2, x); }
 
-// group geometry
+// group geometry (k24f_layout.h): first phase, number of phases, lowest vector-index bit, positions per vector
 constexpr int group_first_phase(int g) { return g < 4 ? 4 * g : 16; }
 constexpr int group_nphases(int g) { return g < 4 ? 4 : 7; }
-constexpr int group_bshift(int g) { return g < 4 ? 19 - 4 * g : 3; }  // lowest vector-index position bit
+constexpr int group_bshift(int g) { return k24f_bshift(g); }
+constexpr int group_vw(int g) { return k24f_vw(g); }          // 4 (8-byte vectors) for the strided groups, 8 for group 4
+constexpr int group_nr(int g) { return 16 * group_vw(g) / 2; }  // packed registers per thread
 
 // packed ACS, tie -> lower (cmpgt_epi16 then min_epi16, viterbi224_sse2.cpp:190-194); acc gets the decision bits
 template <int KB>
@@ -76,13 +83,15 @@ __device__ __forceinline__ i16x2 acs(i16x2 lower, i16x2 upper, unsigned &acc) {
 }
 
 // One trellis step at phase PHI.  pt = the thread-id part of the position (vector-index and low bits zero).
-// Register rho = 4*v + k holds vector v, elements 2k (low field) and 2k+1 (high field).
+// Register rho = (v << KB) | k holds vector v, elements 2k (low field) and 2k+1 (high field); KB = log2(VW) - 1.
 template <int G, int PHI>
-__device__ __forceinline__ void stage(i16x2 (&M)[NR], unsigned s0, unsigned s1, unsigned pt, unsigned (&acc)[4]) {
+__device__ __forceinline__ void stage(i16x2 (&M)[group_nr(G)], unsigned s0, unsigned s1, unsigned pt, unsigned (&acc)[group_nr(G) / 16]) {
     constexpr int b = NB - 1 - PHI;
-    constexpr int BS = group_bshift(G);
+    constexpr int BS = group_bshift(G), NR = group_nr(G), KB = group_vw(G) == 8 ? 2 : 1;
     // static position of register rho, low field
-    auto spos = [](int rho) constexpr -> unsigned { return ((unsigned)(rho >> 2) << BS) | ((unsigned)(rho & 3) << 1); };
+    auto spos = [](int rho) constexpr -> unsigned {
+        return ((unsigned)(rho >> KB) << BS) | ((unsigned)(rho & ((1 << KB) - 1)) << 1);
+    };
     // class offset of the thread part, folded into the symbols
     const unsigned jt = PHI == 0 ? pt : (((pt << PHI) | (pt >> (NB - PHI))) & (N - 1u));
     const unsigned c0 = __popc((2u * jt) & (unsigned)POLY[0]) & 1u, c1 = __popc((2u * jt) & (unsigned)POLY[1]) & 1u;
@@ -91,12 +100,12 @@ __device__ __forceinline__ void stage(i16x2 (&M)[NR], unsigned s0, unsigned s1, 
     const unsigned T[4] = {a0 + a1, x0 + a1, a0 + x1, x0 + x1};  // xor + add   viterbi224_sse2.cpp:159
     constexpr unsigned COMP = (unsigned)Code224::bm_comp;
 #pragma unroll
-    for (int i = 0; i < 4; i++) acc[i] = 0;
+    for (int i = 0; i < NR / 16; i++) acc[i] = 0;
 
     if constexpr (b >= 1) {
-        // register stage: rho bit 0 <-> position bit 1, rho bit 1 <-> position bit 2, rho bits 2..5 <-> bits BS..BS+3
-        constexpr int rb = (b >= 3) ? (2 + b - BS) : (b - 1);
-        static_assert(rb >= 0 && rb < 6, "phase outside this group");
+        // register stage: rho bits 0..KB-1 <-> position bits 1..KB, rho bits KB..KB+3 <-> position bits BS..BS+3
+        constexpr int rb = (b >= BS) ? (KB + b - BS) : (b - 1);
+        static_assert(rb >= 0 && rb < KB + 4 && (b >= BS || b <= KB), "phase outside this group");
         constexpr unsigned ch = cls(rotl23(1u, PHI));  // class of the half bit (position bit 0)
         unsigned TP[4], TQ[4];
 #pragma unroll
@@ -131,12 +140,6 @@ __device__ __forceinline__ void stage(i16x2 (&M)[NR], unsigned s0, unsigned s1, 
     }
 }
 
-// decision byte of vector v from the accumulators: bit = half*4 + k
-__device__ __forceinline__ unsigned dec_byte(const unsigned (&acc)[4], int v) {
-    const unsigned a = acc[v >> 2] >> (4 * (v & 3));
-    return (a & 0xfu) | ((a >> 12) & 0xf0u);
-}
-
 template <int G>
 __global__ __launch_bounds__(256) void acs_k24f_pass_kernel(const int16_t *__restrict__ oldm, int16_t *__restrict__ newm,
                                                             unsigned char *__restrict__ rows, const unsigned char *__restrict__ syms,
@@ -146,14 +149,9 @@ __global__ __launch_bounds__(256) void acs_k24f_pass_kernel(const int16_t *__res
     const int pending = flags[K24F_PENDING];
     if (pending != 0 && pending - 1 < rel_row0 + s_lo) return;
     constexpr int BS = group_bshift(G), P0 = group_first_phase(G), NP = group_nphases(G);
-    const unsigned u = blockIdx.x * blockDim.x + threadIdx.x;  // 65536 threads
-    unsigned pt;  // thread part of the position
-    if constexpr (G < 4) {
-        const unsigned ulo = u & ((1u << (BS - 3)) - 1u), uhi = u >> (BS - 3);
-        pt = (uhi << (BS + 4)) | (ulo << 3);
-    } else {
-        pt = u << 7;
-    }
+    constexpr int NR = group_nr(G), WPT = NR / 16;
+    const unsigned u = blockIdx.x * blockDim.x + threadIdx.x;  // N / (16*VW) threads
+    const unsigned pt = k24f_thread_base(G, u);                // thread part of the position
     i16x2 M[NR];
     // Group 4 holds 16 CONTIGUOUS vectors per thread (256 B), so a direct load would touch 64 separate 256-byte
     // chunks per wave instruction.  Instead each wave streams its 16 KiB tile in lane-linear order (1 KiB per
@@ -181,11 +179,9 @@ __global__ __launch_bounds__(256) void acs_k24f_pass_kernel(const int16_t *__res
     } else {
 #pragma unroll
         for (int v = 0; v < 16; v++) {
-            const uint4 q = *reinterpret_cast<const uint4 *>(oldm + (pt | ((unsigned)v << BS)));
-            M[4 * v] = as_v(q.x);
-            M[4 * v + 1] = as_v(q.y);
-            M[4 * v + 2] = as_v(q.z);
-            M[4 * v + 3] = as_v(q.w);
+            const uint2 q = *reinterpret_cast<const uint2 *>(oldm + (pt | ((unsigned)v << BS)));
+            M[2 * v] = as_v(q.x);
+            M[2 * v + 1] = as_v(q.y);
         }
     }
     sfor<NP>([&](auto I) {
@@ -193,20 +189,11 @@ __global__ __launch_bounds__(256) void acs_k24f_pass_kernel(const int16_t *__res
         constexpr int PHI = P0 + S;
         if (S >= s_lo && S < s_hi) {  // grid-uniform
             const unsigned sy0 = syms[2 * S], sy1 = syms[2 * S + 1];
-            unsigned acc[4];
+            unsigned acc[WPT];
             stage<G, PHI>(M, sy0, sy1, pt, acc);
-            unsigned char *row = rows + (size_t)S * (N / 8);
-            if constexpr (G < 4) {
-#pragma unroll
-                for (int v = 0; v < 16; v++) row[(pt | ((unsigned)v << BS)) >> 3] = (unsigned char)dec_byte(acc, v);
-            } else {
-                unsigned w[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    w[q] = dec_byte(acc, 4 * q) | (dec_byte(acc, 4 * q + 1) << 8) | (dec_byte(acc, 4 * q + 2) << 16) |
-                           (dec_byte(acc, 4 * q + 3) << 24);
-                *reinterpret_cast<uint4 *>(row + (pt >> 3)) = make_uint4(w[0], w[1], w[2], w[3]);
-            }
+            unsigned *row = reinterpret_cast<unsigned *>(rows + (size_t)S * (N / 8)) + (size_t)u * WPT;
+            if constexpr (WPT == 4) *reinterpret_cast<uint4 *>(row) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+            else *reinterpret_cast<uint2 *>(row) = make_uint2(acc[0], acc[1]);
             if (u == 0) {  // state 0 is position 0 in every phase: thread 0, register 0, low field
                 const int new0 = (int)(short)(as_u32(M[0]) & 0xffffu);
                 if (new0 >= Code224::renorm_thr && flags[K24F_PENDING] == 0) flags[K24F_PENDING] = rel_row0 + S + 1;
@@ -228,8 +215,7 @@ __global__ __launch_bounds__(256) void acs_k24f_pass_kernel(const int16_t *__res
     } else {
 #pragma unroll
         for (int v = 0; v < 16; v++)
-            *reinterpret_cast<uint4 *>(newm + (pt | ((unsigned)v << BS))) =
-                make_uint4(as_u32(M[4 * v]), as_u32(M[4 * v + 1]), as_u32(M[4 * v + 2]), as_u32(M[4 * v + 3]));
+            *reinterpret_cast<uint2 *>(newm + (pt | ((unsigned)v << BS))) = make_uint2(as_u32(M[2 * v]), as_u32(M[2 * v + 1]));
     }
 }
 
@@ -249,8 +235,9 @@ __global__ void chainback_k24f_kernel(ChainbackRowsArgs a) {
         unsigned bit = 0;
         if ((int)i < a.rows_written) {
             const unsigned p = rot == 0 ? e : (((e >> rot) | (e << (NB - rot))) & (N - 1u));
-            const unsigned byte = rows[(size_t)i * (N / 8) + (p >> 3)];
-            bit = (byte >> (((p & 1u) << 2) | ((p >> 1) & 3u))) & 1u;
+            unsigned widx, wbit;
+            k24f_locate(p, rot == 0 ? NB - 1 : rot - 1, widx, wbit);
+            bit = (reinterpret_cast<const unsigned *>(rows + (size_t)i * (N / 8))[widx] >> wbit) & 1u;
         }
         e = (bit << (K - 2)) | (e >> 1);
         rot = rot == 0 ? NB - 1 : rot - 1;
@@ -264,7 +251,8 @@ bool k24f_poly_supported(const int *poly) { return poly[0] == k24f::POLY[0] && p
 // one pass: stages [s_lo, s_hi) of group g; rows/syms are those of the group's first phase
 hipError_t launch_k24f_pass(int g, const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,
                             int rel_row0, int s_lo, int s_hi, int *flags, hipStream_t stream) {
-    const dim3 grid(65536 / 256), block(256);
+    const dim3 block(256);
+    const dim3 grid(g < 4 ? 131072 / 256 : 65536 / 256);  // 64 positions per thread in groups 0-3, 128 in group 4
     switch (g) {
     case 0: hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<0>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags); break;
     case 1: hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<1>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags); break;

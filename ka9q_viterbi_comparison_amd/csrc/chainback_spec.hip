@@ -11,6 +11,7 @@
 // instead of six -- the history is far larger than the bytes touched either way.
 #include <hip/hip_runtime.h>
 
+#include "k24f_layout.h"
 #include "kernels.h"
 
 namespace vh {
@@ -35,8 +36,9 @@ __device__ __forceinline__ unsigned fetch_bit(const unsigned char *rows, long r,
             const unsigned w = reinterpret_cast<const unsigned *>(rows)[r * 512L + (rho >> 4) * 128 + t];
             return (w >> ((rho & 15u) + 16u * h)) & 1u;
         } else {
-            const unsigned byte = rows[r * (long)(N / 8) + (p >> 3)];
-            return (byte >> (((p & 1u) << 2) | ((p >> 1) & 3u))) & 1u;
+            unsigned widx, wbit;
+            k24f_locate(p, rot == 0 ? NB - 1 : rot - 1, widx, wbit);
+            return (reinterpret_cast<const unsigned *>(rows + r * (long)(N / 8))[widx] >> wbit) & 1u;
         }
     }
 }

@@ -1,0 +1,40 @@
+// k24f_layout.h -- geometry of the fused K=24 passes (acs_k24f.hip), shared by the kernels, the chainback kernels and
+// the host-side row conversion used by the parity tests.
+//
+// Phase phi = row mod 23 belongs to group g = phi/4 (phi < 16) or 4 (phi >= 16).  A thread of group g holds 16 vectors of
+// VW positions: position p = thread part | (v << BS) | in-vector index, register rho = (v << KB) | k (KB = log2(VW)-1)
+// holds in-vector elements 2k (low field) and 2k+1 (high field).  A decision row is [thread u][NR/16 words] with the
+// decision of position p at bit (rho & 15) + 16*half of word rho >> 4.
+#pragma once
+#if defined(__HIPCC__)
+#define K24F_HD __host__ __device__ __forceinline__
+#else
+#define K24F_HD inline
+#endif
+
+namespace vh {
+
+K24F_HD constexpr int k24f_group_of_phase(int phi) { return phi < 16 ? phi / 4 : 4; }
+K24F_HD constexpr int k24f_bshift(int g) { return g < 4 ? 19 - 4 * g : 3; }  // lowest vector-index position bit
+K24F_HD constexpr int k24f_vw(int g) { return g < 4 ? 4 : 8; }               // positions per vector
+
+// thread part of the position for thread u of group g (vector-index and in-vector bits zero)
+K24F_HD unsigned k24f_thread_base(int g, unsigned u) {
+    const int BS = k24f_bshift(g), LW = g < 4 ? 2 : 3;  // log2(VW)
+    const unsigned ulo = u & ((1u << (BS - LW)) - 1u), uhi = u >> (BS - LW);
+    return (uhi << (BS + 4)) | (ulo << LW);
+}
+
+// position p at phase phi -> 32-bit word index inside the 1 MiB row, bit inside the word
+K24F_HD void k24f_locate(unsigned p, int phi, unsigned &word, unsigned &bit) {
+    const int g = k24f_group_of_phase(phi);
+    const int BS = k24f_bshift(g), LW = g < 4 ? 2 : 3, KB = LW - 1;
+    const unsigned h = p & 1u, k = (p >> 1) & ((1u << KB) - 1u), v = (p >> BS) & 15u;
+    const unsigned ulo = (p >> LW) & ((1u << (BS - LW)) - 1u), uhi = p >> (BS + 4);
+    const unsigned u = (uhi << (BS - LW)) | ulo;
+    const unsigned rho = (v << KB) | k, wpt = (16u << LW) / 32u;  // words per thread = NR/16
+    word = u * wpt + (rho >> 4);
+    bit = (rho & 15u) + 16u * h;
+}
+
+}  // namespace vh

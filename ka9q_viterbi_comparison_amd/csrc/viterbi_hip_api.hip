@@ -16,6 +16,7 @@
 
 #include "../../include/viterbi_hip.h"
 #include "framegen.h"
+#include "k24f_layout.h"
 #include "kernels.h"
 #include "viterbi_codes.h"
 
@@ -536,11 +537,14 @@ int vhip_read_decision_rows(vhip_decoder *p, int frame, int row0, int nrows, uns
         memset(out, 0, (size_t)nrows * p->row_bytes);
         for (int i = 0; i < nrows; i++) {
             HIP_TRY(hipMemcpy(raw.data(), p->d_dec + ((size_t)frame * p->cap_rows + row0 + i) * p->row_bytes, p->row_bytes, hipMemcpyDeviceToHost));
-            const int rot = (row0 + i + 1) % NB;
+            const int rot = (row0 + i + 1) % NB, phi = (row0 + i) % NB;
             unsigned char *o = out + (size_t)i * p->row_bytes;
+            const unsigned *rw = reinterpret_cast<const unsigned *>(raw.data());
             for (unsigned n = 0; n < p->N; n++) {
                 const unsigned pos = rot == 0 ? n : (((n >> rot) | (n << (NB - rot))) & (p->N - 1));
-                if ((raw[pos >> 3] >> (((pos & 1u) << 2) | ((pos >> 1) & 3u))) & 1u) o[n >> 3] |= (unsigned char)(1u << (n & 7));
+                unsigned widx, wbit;
+                vh::k24f_locate(pos, phi, widx, wbit);
+                if ((rw[widx] >> wbit) & 1u) o[n >> 3] |= (unsigned char)(1u << (n & 7));
             }
         }
         return 0;
