@@ -40,3 +40,14 @@ def test_harness_json_schema_and_ber(tmp_path):
     assert r.returncode == 0, r.stderr
     e = json.load(open(out))[0]
     assert e["K"] == 24 and e["total_bit_errors"] == 0  # BER from the nbits+K-1 call
+
+
+@pytest.mark.gpu
+def test_reference_style_bindings_decode():
+    """harness/adapter_check: the reference's test_third_party call sequence over host buffers, through
+    include/hip_interface.h and through a ka9q_interface-shaped five-function adapter."""
+    exe = os.path.join(ROOT, "harness", "adapter_check")
+    assert os.path.exists(exe), "build it: make -C harness"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all bindings ok" in r.stdout
