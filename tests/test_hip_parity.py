@@ -316,3 +316,39 @@ def test_two_handles_two_streams_and_reuse():
             assert np.array_equal(r2[f], oracle_decode(C.SPIRAL47, y2[f], steps, B * 8)["data"])
     d1.close()
     d2.close()
+
+
+@pytest.mark.parametrize("code", [C.KA9Q27, C.SPIRAL47, C.KA9Q29, C.SPIRAL49, C.SPIRAL27, C.KA9Q615, C.KA9Q224])
+def test_arbitrary_polynomials(code):
+    """Polynomials other than the harness set take the any-polynomial kernels (acs_lds / acs_k24); branch tables are
+    per handle, so two handles with different polynomials coexist (the reference keeps one process-global table,
+    viterbi27_sse2.cpp:26-28,61-70).  Asking for the specialised kernels with such polynomials is an error."""
+    from ka9q_viterbi_comparison_amd._lib import VhipError
+    from ka9q_viterbi_comparison_amd.decoder import gen_frames_host, noise_q12
+
+    spec = spec_of(code)
+    rng = np.random.default_rng(1000 + code)
+    B = 8 if spec.K == 24 else 16
+    steps = B * 8 + spec.K - 1
+    steps -= 0 if spec_is_incremental(code) else steps % 2
+    for trial in range(2):
+        poly = [int(rng.integers(0, 1 << (spec.K - 2))) * 2 + 1 + (1 << (spec.K - 1)) for _ in range(spec.R)]
+        nframes = 1 if spec.K == 24 else 5
+        payload, syms = gen_frames_host(spec, 7 + trial, 0, nframes, B, C.SOFT_AMP_Q16, noise_q12(spec.R, 64.0, spec.ebn0_db), poly=poly)
+        syms = np.ascontiguousarray(syms[:, :steps * spec.R])
+        dec = HipViterbi(spec.name, steps, nframes=nframes, poly=poly)
+        assert dec.variant in (VARIANT_LDS, VARIANT_HBM)
+        dec.reset()
+        dec.update(syms, nbits=steps)
+        data, _ = dec.chainback(B * 8)
+        for f in range(nframes):
+            o = OracleDecoder(code, poly, steps)
+            o.update(syms[f], steps)
+            ref, _ = o.chainback(B * 8)
+            assert np.array_equal(dec.decision_rows(f, 0, steps), o.rows(steps)), (poly, f)
+            assert np.array_equal(dec.metrics(f), o.metrics())
+            assert np.array_equal(data[f], ref)
+            o.close()
+        dec.close()
+        with pytest.raises(VhipError):
+            HipViterbi(spec.name, steps, nframes=1, poly=poly, variant=VARIANT_HBM_FUSED if spec.K == 24 else VARIANT_REGS)
