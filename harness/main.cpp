@@ -32,6 +32,7 @@ struct Args {
     bool hard = false;
     unsigned long long seed = 0x5EED;
     int payload_bytes = 0;  // 0 = the reference's size for the code
+    int gpus = 1;           // frame-range shards, one per device
 };
 
 struct CodeBlock {
@@ -54,7 +55,7 @@ const CodeBlock BLOCKS[] = {
 void usage(const char *argv0) {
     fprintf(stderr,
             "usage: %s [-t seconds] [-n samples] [-o file.json] [--frames N] [--codes 27,47,...] [--ebn0 dB | --hard]\n"
-            "          [--payload-bytes B] [--seed S]\n",
+            "          [--payload-bytes B] [--seed S] [--gpus N]\n",
             argv0);
 }
 
@@ -72,6 +73,7 @@ bool parse(int argc, char **argv, Args &a) {
         else if (k == "--hard") a.hard = true;
         else if (k == "--seed") { if (!(v = val())) return false; a.seed = strtoull(v, nullptr, 0); }
         else if (k == "--payload-bytes") { if (!(v = val())) return false; a.payload_bytes = atoi(v); }
+        else if (k == "--gpus") { if (!(v = val())) return false; a.gpus = atoi(v); }
         else if (k == "-h" || k == "--help") return false;
         else { fprintf(stderr, "unknown argument %s\n", k.c_str()); return false; }
     }
@@ -112,66 +114,91 @@ int main(int argc, char **argv) {
     Args args;
     if (!parse(argc, argv, args)) { usage(argv[0]); return 1; }
     if (vhip_device_count() < 1) { fprintf(stderr, "no HIP device: this harness has no CPU decode path\n"); return 2; }
+    if (args.gpus < 1 || args.gpus > vhip_device_count()) { fprintf(stderr, "--gpus %d but %d device(s) visible\n", args.gpus, vhip_device_count()); return 1; }
     FILE *fp = fopen(args.output.c_str(), "w");
     if (!fp) { fprintf(stderr, "Failed to open file for writing: '%s'\n", args.output.c_str()); return 1; }
     fprintf(fp, "[\n");
     bool first = true;
     for (const CodeBlock &cb : BLOCKS) {
         if (!selected(args.codes, cb.name)) continue;
-        const int frames = args.frames > 0 ? args.frames : cb.default_frames;
+        int frames = args.frames > 0 ? args.frames : cb.default_frames;  // per GPU until the shards are built
         const int bytes = args.payload_bytes > 0 ? args.payload_bytes : cb.ref_payload_bytes;
         const size_t decode_bits = (size_t)bytes * 8, transmit_bits = decode_bits + cb.K - 1, symbols = transmit_bits * cb.R;
         fprintf(stderr, "[test_run]\nK=%d, R=%d\ntotal_input_bytes = %d, frames = %d\n", cb.K, cb.R, bytes, frames);
-        unsigned char *d_payload, *d_syms, *d_out;
-        HIPCHK(hipMalloc((void **)&d_payload, (size_t)frames * bytes));
-        HIPCHK(hipMalloc((void **)&d_syms, (size_t)frames * symbols));
-        HIPCHK(hipMalloc((void **)&d_out, (size_t)frames * bytes));
+        // One shard of `frames` frames per GPU (frames are independent -> frame-range sharding, no
+        // collective).  All shards are driven from this thread: every call is asynchronous on its handle's stream, so
+        // a phase is issued to all devices and then awaited; the phase time is first issue -> last completion.
+        struct Shard {
+            int device = 0;
+            unsigned char *d_payload = nullptr, *d_syms = nullptr, *d_out = nullptr;
+            vhip_decoder *dec = nullptr;
+        };
+        std::vector<Shard> shards((size_t)args.gpus);
         const double ebn0 = args.ebn0 > 1e8 ? cb.default_ebn0 : args.ebn0;
         const int amp_q16 = args.hard ? (int)(127.5 * 65536) : 64 * 65536;
         const int nq = args.hard ? 0 : vhip_noise_q12_from_ebn0(cb.R, 64.0, ebn0);
-        if (vhip_gen_frames_dev(cb.K, cb.R, cb.poly, args.seed, 0, frames, bytes, amp_q16, nq, d_payload, d_syms, nullptr) != 0) {
-            fprintf(stderr, "%s\n", vhip_last_error());
-            return 2;
+        for (int d = 0; d < args.gpus; d++) {
+            Shard &sh = shards[(size_t)d];
+            sh.device = d;
+            HIPCHK(hipSetDevice(d));
+            HIPCHK(hipMalloc((void **)&sh.d_payload, (size_t)frames * bytes));
+            HIPCHK(hipMalloc((void **)&sh.d_syms, (size_t)frames * symbols));
+            HIPCHK(hipMalloc((void **)&sh.d_out, (size_t)frames * bytes));
+            if (vhip_gen_frames_dev(cb.K, cb.R, cb.poly, args.seed, (uint64_t)d * (uint64_t)frames, frames, bytes, amp_q16, nq,
+                                    sh.d_payload, sh.d_syms, nullptr) != 0) {
+                fprintf(stderr, "%s\n", vhip_last_error());
+                return 2;
+            }
+            HIPCHK(hipDeviceSynchronize());
+            sh.dec = vhip_create(cb.code, cb.poly, (int)transmit_bits, frames);  // bound to the current device
+            if (!sh.dec) { fprintf(stderr, "%s\n", vhip_last_error()); return 2; }
         }
-        HIPCHK(hipDeviceSynchronize());
-        vhip_decoder *dec = vhip_create(cb.code, cb.poly, (int)transmit_bits, frames);
-        if (!dec) { fprintf(stderr, "%s\n", vhip_last_error()); return 2; }
+        auto sync_all = [&]() { for (Shard &sh : shards) vhip_sync(sh.dec); };
         std::vector<uint64_t> init_ns, update_ns, chainback_ns;
         const auto t_total = clk::now();
         for (size_t i = 0;; i++) {
             const float elapsed = (float)ns_since(t_total) * 1e-9f;
             if (elapsed > args.sampling_time && i > args.minimum_samples) break;
-            HIPCHK(hipMemsetAsync(d_out, 0, (size_t)frames * bytes, nullptr));  // main.cpp:262
-            HIPCHK(hipDeviceSynchronize());
+            for (Shard &sh : shards) {
+                HIPCHK(hipSetDevice(sh.device));
+                HIPCHK(hipMemsetAsync(sh.d_out, 0, (size_t)frames * bytes, nullptr));  // main.cpp:262
+                HIPCHK(hipDeviceSynchronize());
+            }
             auto t = clk::now();
-            vhip_init(dec, 0);
-            vhip_sync(dec);
+            for (Shard &sh : shards) vhip_init(sh.dec, 0);
+            sync_all();
             init_ns.push_back(ns_since(t));
             t = clk::now();
-            if (vhip_update_dev(dec, d_syms, (int)transmit_bits) != 0) { fprintf(stderr, "%s\n", vhip_last_error()); return 2; }
-            vhip_sync(dec);
+            for (Shard &sh : shards)
+                if (vhip_update_dev(sh.dec, sh.d_syms, (int)transmit_bits) != 0) { fprintf(stderr, "%s\n", vhip_last_error()); return 2; }
+            sync_all();
             update_ns.push_back(ns_since(t));
             t = clk::now();
             // K=24: the reference's own call (nbits = payload bits) is what is timed; it does not decode correctly
             // (SURVEY.md §0.4), so its BER is reported from a separate nbits+K-1 call below.
-            if (vhip_chainback_dev(dec, d_out, (unsigned)decode_bits, 0) != 0) { fprintf(stderr, "%s\n", vhip_last_error()); return 2; }
-            vhip_sync(dec);
+            for (Shard &sh : shards)
+                if (vhip_chainback_dev(sh.dec, sh.d_out, (unsigned)decode_bits, 0) != 0) { fprintf(stderr, "%s\n", vhip_last_error()); return 2; }
+            sync_all();
             chainback_ns.push_back(ns_since(t));
         }
-        long long errors;
-        if (cb.K == 24) {
-            unsigned char *d_long;
-            const size_t lb = (transmit_bits + 7) / 8;
-            HIPCHK(hipMalloc((void **)&d_long, (size_t)frames * lb));
-            vhip_chainback_dev(dec, d_long, (unsigned)transmit_bits, 0);
-            vhip_sync(dec);
-            errors = 0;
-            for (int f = 0; f < frames; f++)
-                errors += vhip_count_bit_errors_dev(d_long + (size_t)f * lb, d_payload + (size_t)f * bytes, (size_t)bytes, nullptr);
-            HIPCHK(hipFree(d_long));
-        } else {
-            errors = vhip_count_bit_errors_dev(d_out, d_payload, (size_t)frames * bytes, nullptr);
+        long long errors = 0;
+        for (Shard &sh : shards) {
+            HIPCHK(hipSetDevice(sh.device));
+            if (cb.K == 24) {
+                unsigned char *d_long;
+                const size_t lb = (transmit_bits + 7) / 8;
+                HIPCHK(hipMalloc((void **)&d_long, (size_t)frames * lb));
+                vhip_chainback_dev(sh.dec, d_long, (unsigned)transmit_bits, 0);
+                vhip_sync(sh.dec);
+                for (int f = 0; f < frames; f++)
+                    errors += vhip_count_bit_errors_dev(d_long + (size_t)f * lb, sh.d_payload + (size_t)f * bytes, (size_t)bytes, nullptr);
+                HIPCHK(hipFree(d_long));
+            } else {
+                errors += vhip_count_bit_errors_dev(sh.d_out, sh.d_payload, (size_t)frames * bytes, nullptr);
+            }
         }
+        const int frames_per_gpu = frames;
+        frames *= args.gpus;  // whole-job sizes below
         const size_t total_bits = (size_t)frames * decode_bits;
         const double hbm_bytes = cb.K == 24 ? 34603010.0 * transmit_bits * frames
                                             : (double)(cb.R + (1 << (cb.K - 1)) / 8) * transmit_bits * frames;
@@ -183,7 +210,7 @@ int main(int argc, char **argv) {
         first = false;
         fprintf(fp, "  \"name\": \"hip\",\n  \"K\": %d,\n  \"R\": %d,\n  \"poly\": [", cb.K, cb.R);
         for (int r = 0; r < cb.R; r++) fprintf(fp, "%s%d", r ? "," : "", cb.poly[r]);
-        fprintf(fp, "],\n  \"frames\": %d,\n", frames);
+        fprintf(fp, "],\n  \"frames\": %d,\n  \"gpus\": %d,\n  \"frames_per_gpu\": %d,\n", frames, args.gpus, frames_per_gpu);
         fprintf(fp, "  \"total_input_bytes\": %zu,\n  \"total_transmit_bits\": %zu,\n  \"total_output_symbols\": %zu,\n",
                 (size_t)bytes * frames, transmit_bits * frames, symbols * frames);
         fprintf(fp, "  \"sampling_time\": %f,\n  \"minimum_samples\": %zu,\n  \"total_samples\": %zu,\n", args.sampling_time,
@@ -194,15 +221,18 @@ int main(int argc, char **argv) {
         print_u64_array(fp, update_ns);
         fprintf(fp, ",\n  \"chainback_ns\": ");
         print_u64_array(fp, chainback_ns);
-        fprintf(fp, ",\n  \"hbm_bytes_per_update\": %.0f,\n  \"roofline_fraction\": %.5f,\n", hbm_bytes, hbm_bytes / (upd_mean * 1e-9) / 8e12);
+        fprintf(fp, ",\n  \"hbm_bytes_per_update\": %.0f,\n  \"roofline_fraction\": %.5f,\n", hbm_bytes, hbm_bytes / (upd_mean * 1e-9) / (8e12 * args.gpus));
         fprintf(fp, "  \"total_bits\": %zu,\n  \"total_bit_errors\": %lld,\n  \"bit_error_rate\": %f\n}", total_bits, errors,
                 (double)errors / (double)total_bits);
         fprintf(stderr, "o hip (%.6f)  update %.1f Msym/s\n", (double)errors / (double)total_bits,
                 (double)symbols * frames / (upd_mean * 1e-9) / 1e6);
-        vhip_delete(dec);
-        HIPCHK(hipFree(d_payload));
-        HIPCHK(hipFree(d_syms));
-        HIPCHK(hipFree(d_out));
+        for (Shard &sh : shards) {
+            HIPCHK(hipSetDevice(sh.device));
+            vhip_delete(sh.dec);
+            HIPCHK(hipFree(sh.d_payload));
+            HIPCHK(hipFree(sh.d_syms));
+            HIPCHK(hipFree(sh.d_out));
+        }
     }
     fprintf(fp, "\n]\n");
     fclose(fp);

@@ -95,6 +95,14 @@ int init_start_of(int code) {
     return 0;
 }
 
+// a handle is bound to the device that was current at create(); callers may since have switched devices
+int use_device(const vhip_decoder *p) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == p->device) return 0;
+    HIP_TRY(hipSetDevice(p->device));
+    return 0;
+}
+
 int ensure_stage(unsigned char **buf, size_t *cap, size_t need, size_t *total) {
     if (*cap >= need) return 0;
     if (*buf) {
@@ -307,6 +315,7 @@ vhip_decoder *vhip_create(int code, const int *poly, int len, int nframes) {
 
 void vhip_delete(vhip_decoder *p) {
     if (!p) return;  // delete(NULL) is a no-op in the reference too (viterbi27_sse2.cpp:108-115)
+    (void)use_device(p);
     if (p->d_dec) (void)hipFree(p->d_dec);
     if (p->d_metrics) (void)hipFree(p->d_metrics);
     if (p->d_flags) (void)hipFree(p->d_flags);
@@ -323,6 +332,7 @@ int vhip_set_stream(vhip_decoder *p, void *stream) {
 
 int vhip_sync(vhip_decoder *p) {
     if (!p) return fail("sync: NULL handle");
+    if (use_device(p) != 0) return -1;
     HIP_TRY(hipStreamSynchronize(p->stream));
     return 0;
 }
@@ -357,6 +367,7 @@ size_t vhip_device_bytes(const vhip_decoder *p) { return p ? p->total_bytes : 0;
 // init_viterbi27_sse2 (viterbi27_sse2.cpp:42-54) for every frame of the handle
 int vhip_init(vhip_decoder *p, int starting_state) {
     if (!p) return fail("init: NULL handle");  // viterbi224_sse2.cpp:36-37 returns -1 on NULL
+    if (use_device(p) != 0) return -1;
     const unsigned start = (unsigned)starting_state & (p->N - 1);
     const int ia = init_all_of(p->code), is = init_start_of(p->code);
     if (p->code == VHIP_KA9Q224) {
@@ -375,6 +386,7 @@ int vhip_init(vhip_decoder *p, int starting_state) {
 
 int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
     if (!p) return fail("update: NULL handle");
+    if (use_device(p) != 0) return -1;
     if (nbits <= 0) return 0;
     int steps = nbits, row0 = p->pos;
     if (!p->incremental) {  // spiral47.cpp:536-538: restart at row 0, nbits/2 double steps
@@ -430,6 +442,7 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
 
 int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbits, unsigned int endstate) {
     if (!p) return fail("chainback: NULL handle");
+    if (use_device(p) != 0) return -1;
     if (nbits == 0) return 0;
     if (p->variant == VHIP_VARIANT_HBM_FUSED) {
         vh::ChainbackRowsArgs a;
@@ -496,6 +509,7 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
 
 int vhip_update(vhip_decoder *p, const unsigned char *syms, int nbits) {
     if (!p) return fail("update: NULL handle");
+    if (use_device(p) != 0) return -1;
     if (nbits <= 0) return 0;
     const size_t bytes = (size_t)p->nframes * (size_t)nbits * p->R;
     if (ensure_stage(&p->d_syms_stage, &p->syms_stage_bytes, bytes, &p->total_bytes) != 0) return -1;
@@ -507,6 +521,7 @@ int vhip_update(vhip_decoder *p, const unsigned char *syms, int nbits) {
 
 int vhip_chainback(vhip_decoder *p, unsigned char *data, unsigned int nbits, unsigned int endstate) {
     if (!p) return fail("chainback: NULL handle");
+    if (use_device(p) != 0) return -1;
     int ret = 0;
     if (p->code == VHIP_KA9Q615 && p->nframes == 1) {
         // chainback_viterbi615_sse2 returns old_metrics->s[endstate]            viterbi615_sse2.cpp:76,90
@@ -527,6 +542,7 @@ int vhip_chainback(vhip_decoder *p, unsigned char *data, unsigned int nbits, uns
 
 int vhip_read_decision_rows(vhip_decoder *p, int frame, int row0, int nrows, unsigned char *out) {
     if (!p) return fail("read_decision_rows: NULL handle");
+    if (use_device(p) != 0) return -1;
     if (frame < 0 || frame >= p->nframes || row0 < 0 || nrows < 0 || row0 + nrows > p->cap_rows)
         return fail("read_decision_rows: out of range");
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -597,6 +613,7 @@ int vhip_read_decision_rows(vhip_decoder *p, int frame, int row0, int nrows, uns
 
 int vhip_read_metrics(vhip_decoder *p, int frame, int32_t *out) {
     if (!p) return fail("read_metrics: NULL handle");
+    if (use_device(p) != 0) return -1;
     if (frame < 0 || frame >= p->nframes) return fail("read_metrics: out of range");
     HIP_TRY(hipStreamSynchronize(p->stream));
     std::vector<int16_t> tmp(p->N);
