@@ -482,7 +482,7 @@ bool regs_poly_supported(int code, const int *poly) {
 bool regs_lanes_supported(int code, int lb) {
     switch (code) {
     case VHIP_KA9Q27: case VHIP_SPIRAL47: case VHIP_SPIRAL27: return lb >= 0 && lb <= 2;
-    case VHIP_KA9Q29: case VHIP_SPIRAL49: case VHIP_SPIRAL29: return lb >= 1 && lb <= 2;
+    case VHIP_KA9Q29: case VHIP_SPIRAL49: case VHIP_SPIRAL29: return lb >= 0 && lb <= 2;
     }
     return false;
 }
@@ -513,10 +513,12 @@ hipError_t launch_acs_regs(int code, int lb, const AcsRegsArgs &a, hipStream_t s
         if (lb == 2) return launch_regs<Code47, Poly47, 2>(a, stream);
         break;
     case VHIP_KA9Q29:
+        if (lb == 0) return launch_regs<Code29, Poly29, 0>(a, stream);
         if (lb == 1) return launch_regs<Code29, Poly29, 1>(a, stream);
         if (lb == 2) return launch_regs<Code29, Poly29, 2>(a, stream);
         break;
     case VHIP_SPIRAL49:
+        if (lb == 0) return launch_regs<Code49, Poly49, 0>(a, stream);
         if (lb == 1) return launch_regs<Code49, Poly49, 1>(a, stream);
         if (lb == 2) return launch_regs<Code49, Poly49, 2>(a, stream);
         break;
@@ -526,6 +528,7 @@ hipError_t launch_acs_regs(int code, int lb, const AcsRegsArgs &a, hipStream_t s
         if (lb == 2) return launch_regs<CodeS27, Poly27, 2>(a, stream);
         break;
     case VHIP_SPIRAL29:
+        if (lb == 0) return launch_regs<CodeS29, Poly29, 0>(a, stream);
         if (lb == 1) return launch_regs<CodeS29, Poly29, 1>(a, stream);
         if (lb == 2) return launch_regs<CodeS29, Poly29, 2>(a, stream);
         break;
@@ -656,7 +659,7 @@ hipError_t launch_chainback_regs(const ChainbackRegsArgs &a, hipStream_t stream)
         hipLaunchKernelGGL((chainback_regs_pipe_kernel<KK, LBB, DD>), dim3(blocks), dim3(64), 0, stream, a);     \
         return hipGetLastError();                                                                                \
     }
-    VH_CB(7, 0, 16) VH_CB(7, 1, 16) VH_CB(7, 2, 16) VH_CB(9, 1, 8) VH_CB(9, 2, 8)
+    VH_CB(7, 0, 16) VH_CB(7, 1, 16) VH_CB(7, 2, 16) VH_CB(9, 0, 8) VH_CB(9, 1, 8) VH_CB(9, 2, 8)
 #undef VH_CB
     hipLaunchKernelGGL(chainback_regs_kernel, dim3(blocks), dim3(64), 0, stream, a);
     return hipGetLastError();

@@ -27,7 +27,7 @@ def variants_for(code):
         return [VARIANT_LDS]
     if code in (C.KA9Q27, C.SPIRAL47, C.SPIRAL27):
         return [VARIANT_LDS, regs(0), regs(1), regs(2)]
-    return [VARIANT_LDS, regs(1), regs(2)]
+    return [VARIANT_LDS, regs(0), regs(1), regs(2)]
 
 
 def oracle_decode(code, syms, steps, nbits, endstate=0, start=0, splits=None):
