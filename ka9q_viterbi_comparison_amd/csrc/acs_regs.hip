@@ -651,9 +651,102 @@ __global__ __launch_bounds__(64) void chainback_regs_pipe_kernel(ChainbackRegsAr
     }
 }
 
+// LDS-staged form: one wave per 64 frames streams the decision history of its groups through a double-buffered LDS
+// ring with direct global->LDS loads (global_load_lds_dwordx4, 1 KiB per instruction, no VGPR staging), D rows per
+// buffer; the loads of block n+1 are in flight while block n is walked out of LDS.  Same walk, same bytes.
+template <int K, int LB, int D>
+__global__ __launch_bounds__(64) void chainback_regs_lds_kernel(ChainbackRegsArgs a) {
+    constexpr int NB = K - 1, L = 1 << LB;
+    constexpr unsigned N = 1u << NB;
+    constexpr int NR = N / (2 * L), NRW = NR < 16 ? NR : 16, DW = NR / NRW, WB = NRW == 16 ? 4 : 2;
+    constexpr int FPW = 64 / L, GPW = L;   // frames per group, groups per wave
+    constexpr int RS = DW * 64 * WB;       // bytes of one row of one group
+    constexpr int GB = D * RS;             // bytes of one group's block
+    constexpr int BUF = GPW * GB;          // bytes per buffer
+    static_assert(GB % 1024 == 0 && 2 * BUF <= 65536, "block geometry");
+    constexpr int add = (NB < 8) ? 8 - NB : 0, sub = (NB > 8) ? NB - 8 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char ring[2 * BUF];
+
+    const unsigned lane = threadIdx.x;
+    const long f0 = (long)blockIdx.x * 64 + lane;
+    const bool active = f0 < a.nframes;
+    const long f = active ? f0 : (long)a.nframes - 1;
+    const unsigned gl = lane / FPW, fl = (unsigned)(f0 % FPW);
+    unsigned char *out = a.data + f * (long)a.data_stride;
+    const unsigned char *wave_dec = a.dec + ((long)blockIdx.x * GPW * a.cap_rows) * RS;  // group gw0 = blockIdx.x*GPW
+    const unsigned char *gbase = a.dec + ((f / FPW) * a.cap_rows) * (long)RS + (fl * L) * WB;  // for the remainder walk
+    unsigned e = (a.endstate % N) << add;
+    int rot = (int)(a.nbits % NB);
+
+    auto advance = [&](unsigned i, unsigned k) {
+        e = (e >> 1) | (k << (K - 2 + add));
+        if ((i & 7u) == 0 && active) out[i >> 3] = (unsigned char)(e >> sub);
+        rot = rot == 0 ? NB - 1 : rot - 1;
+    };
+    auto locate = [&](unsigned &woff, unsigned &bit) {  // byte offset inside a group row, bit inside the word
+        const unsigned st = e >> add;
+        const unsigned p = rot == 0 ? st : (((st >> rot) | (st << (NB - rot))) & (N - 1));
+        const unsigned lam = p & (L - 1), h = (p >> LB) & 1u, rho = p >> (LB + 1);
+        woff = ((rho / NRW) * 64 + fl * L + lam) * WB;
+        bit = (rho % NRW) + NRW * h;
+    };
+    // rows [r_lo, r_lo + D) of every group of this wave -> buffer b
+    auto issue = [&](int b, long r_lo) {
+#pragma unroll
+        for (int g = 0; g < GPW; g++) {
+            const unsigned char *src = wave_dec + ((long)g * a.cap_rows + r_lo) * RS + lane * 16;
+#pragma unroll
+            for (int c = 0; c < GB / 1024; c++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + c * 1024),
+                                                 (__attribute__((address_space(3))) void *)(ring + b * BUF + g * GB + c * 1024), 16, 0, 0);
+        }
+    };
+
+    unsigned i = a.nbits;
+    while (i > 0 && (long)(i - 1) + NB >= a.rows_written) {  // rows never written read as zero
+        --i;
+        advance(i, 0);
+    }
+    const unsigned nblk = i / D;
+    if (nblk > 0) {
+        issue(0, (long)(i - D) + NB);
+        for (unsigned b = 0; b < nblk; b++) {
+            __syncthreads();  // block b has landed (hipcc drains vmcnt here); every lane is done with the other buffer
+            if (b + 1 < nblk) issue((int)((b + 1) & 1u), (long)(i - 2 * D) + NB);
+            const unsigned char *blk = ring + (b & 1u) * BUF + gl * GB;
+#pragma unroll 4
+            for (int d = 0; d < D; d++) {
+                unsigned woff, bit;
+                locate(woff, bit);
+                const unsigned char *wp = blk + (D - 1 - d) * RS + woff;
+                const unsigned word = WB == 4 ? *reinterpret_cast<const unsigned *>(wp) : *reinterpret_cast<const unsigned short *>(wp);
+                advance(i - 1 - d, (word >> bit) & 1u);
+            }
+            i -= D;
+        }
+    }
+    while (i > 0) {  // fewer than D rows left: read them from global memory
+        --i;
+        unsigned woff, bit;
+        locate(woff, bit);
+        const unsigned char *wp = gbase + ((long)i + NB) * RS + woff - (fl * L) * WB;
+        const unsigned word = WB == 4 ? *reinterpret_cast<const unsigned *>(wp) : *reinterpret_cast<const unsigned short *>(wp);
+        advance(i, (word >> bit) & 1u);
+    }
+}
+
 hipError_t launch_chainback_regs(const ChainbackRegsArgs &a, hipStream_t stream) {
     const int blocks = (a.nframes + 63) / 64;
     const bool pipe = getenv("VHIP_CHAINBACK_SIMPLE") == nullptr;
+    if (pipe && !getenv("VHIP_CHAINBACK_PIPE")) {  // default: LDS-staged (K=9: 0.93 -> 0.48 ms on 32768 frames)
+#define VH_CBL(KK, LBB, DD)                                                                                      \
+    if (a.K == KK && a.lay.lb == LBB) {                                                                          \
+        hipLaunchKernelGGL((chainback_regs_lds_kernel<KK, LBB, DD>), dim3(blocks), dim3(64), 0, stream, a);      \
+        return hipGetLastError();                                                                                \
+    }
+        VH_CBL(7, 0, 32) VH_CBL(7, 1, 32) VH_CBL(7, 2, 32) VH_CBL(9, 0, 16) VH_CBL(9, 1, 16) VH_CBL(9, 2, 16)
+#undef VH_CBL
+    }
 #define VH_CB(KK, LBB, DD)                                                                                       \
     if (pipe && a.K == KK && a.lay.lb == LBB) {                                                                  \
         hipLaunchKernelGGL((chainback_regs_pipe_kernel<KK, LBB, DD>), dim3(blocks), dim3(64), 0, stream, a);     \
