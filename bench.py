@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--ebn0", type=float, default=None, help="Eb/N0 in dB; 'hard' symbols if --hard")
     ap.add_argument("--hard", action="store_true", help="reference-style noise-free 0/255 symbols")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--chunk-frames", type=int, default=None, help="frames per handle (default: all, halved until the history fits)")
+    ap.add_argument("--hbm-budget-gb", type=float, default=200.0, help="decision-history budget per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", action="store_true", help="also report value_pipelined: steps alternated over two handles/streams")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -156,21 +158,35 @@ def main():
     # synthetic frames generated on the device, distinct per rank (frame ids rank*frames ...)
     frame_lo, _ = weak_range(frames, rank)
     gen_frames_dev(spec, 0x5EED, frame_lo, frames, payload_bytes, amp_q16, nq, d_payload, d_syms, stream.cuda_stream)
-    dec = HipViterbi(args.code, nsteps, nframes=frames, variant=args.variant, stream=stream.cuda_stream)
+    # The decision history (N/8 bytes per frame-step) must fit in HBM next to the symbols: large K=15 batches are
+    # decoded in chunks of frames that reuse one handle (SURVEY.md §7 "K=15 capacity"); a step still covers all frames.
+    dec_bytes_per_frame = (nsteps + spec.K) * ((1 << (spec.K - 1)) // 8)
+    budget = int(args.hbm_budget_gb * 1e9)
+    chunk = frames if args.chunk_frames is None else args.chunk_frames
+    while chunk > 64 and chunk * dec_bytes_per_frame > budget:
+        chunk = (chunk + 1) // 2
+    nchunks = (frames + chunk - 1) // chunk
+    assert frames % chunk == 0, "frames must be a multiple of the chunk size"
+    dec = HipViterbi(args.code, nsteps, nframes=chunk, variant=args.variant, stream=stream.cuda_stream)
     # K=24's own chainback call convention needs nbits+K-1 to decode correctly; the harness call
     # (nbits = payload bits) is what is timed, as in the reference.
     cb_bits = payload_bits
+    sym_chunk, out_chunk = chunk * nsteps * spec.R, chunk * payload_bytes
 
     def one_pass(ev=None):
-        dec.reset()
-        if ev:
-            ev[0].record(stream)
-        dec.update(d_syms, nbits=nsteps)
-        if ev:
-            ev[1].record(stream)
-        dec.chainback(cb_bits, out=d_out)
-        if ev:
-            ev[2].record(stream)
+        for c in range(nchunks):
+            first, last = c == 0, c == nchunks - 1
+            dec.reset()
+            if ev and first:
+                ev[0].record(stream)
+            dec.update(d_syms[c * sym_chunk:(c + 1) * sym_chunk], nbits=nsteps)
+            if ev and nchunks == 1:
+                ev[1].record(stream)
+            dec.chainback(cb_bits, out=d_out[c * out_chunk:(c + 1) * out_chunk])
+            if ev and last:
+                if nchunks > 1:
+                    ev[1].record(stream)  # chunked: per-kernel split not available, report the whole pass as update
+                ev[2].record(stream)
 
     def barrier():
         shard_barrier(dev)
@@ -189,7 +205,7 @@ def main():
     # Optional extra (not `value`): the same K steps issued alternately on two handles / two streams, so that the
     # HBM-bound chainback of one batch overlaps the VALU-bound update of the next (steady-state serving throughput).
     pipelined = None
-    if args.pipeline and spec.K <= 15:
+    if args.pipeline and spec.K <= 15 and nchunks == 1:
         s2 = torch.cuda.Stream(device=dev)
         dec2 = HipViterbi(args.code, nsteps, nframes=frames, variant=args.variant, stream=s2.cuda_stream)
         d_out2 = torch.zeros_like(d_out)
@@ -246,7 +262,7 @@ def main():
             "data": "synthetic" + (" hard 0/255 symbols" if args.hard else f" AWGN Eb/N0={ebn0} dB, amplitude {C.SOFT_AMP}") + ", generated on device",
             "config": {"workload": f"viterbi{spec.name}: K={spec.K} r=1/{spec.R}, {frames} frames/GPU x {payload_bits} info bits "
                                    f"({nsteps} trellis steps, {nsteps * spec.R} symbols/frame)",
-                       "frames_per_gpu": frames, "payload_bits": payload_bits, "variant": dec.variant,
+                       "frames_per_gpu": frames, "chunk_frames": chunk, "payload_bits": payload_bits, "variant": dec.variant,
                        "parallelism": f"frame-shard x{n_gpus}, no collective"},
             "update_msym_s": round(frames * nsteps * spec.R * n_gpus / (upd_ms * 1e-3) / 1e6, 6),
             "chainback_mbit_s": round(frames * cb_bits * n_gpus / (cb_ms * 1e-3) / 1e6, 3),

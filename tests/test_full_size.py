@@ -107,3 +107,41 @@ def test_sweep_codes_roundtrip(name, frames):
         spec, d_payload, d_syms, d_out = decode_batch(name, frames, bits, hard=False, variant=variant)
         sums.append(zlib.crc32(d_out.cpu().numpy().tobytes()))
     assert sums[0] == sums[1]
+
+
+@pytest.mark.parametrize("name", ["27", "47", "29", "49", "spiral27", "spiral29", "615"])
+def test_pure_noise_cross_kernel_stress(name):
+    """Uniform random symbols (no codeword underneath) drive the path metrics to their widest spread -- the regime of
+    wrap-around / saturation / tie corner cases.  Large batches, every kernel family: decoded bytes and final path
+    metrics must agree between the independent implementations (the LDS kernel is oracle-checked frame by frame in
+    test_hip_parity.py), and sampled frames must equal the oracle."""
+    spec = C.CODES[name]
+    frames = 4096 if spec.K < 15 else 64
+    bits = 1024 if spec.K < 15 else 256
+    steps = bits + spec.K - 1
+    steps -= steps % 2
+    g = torch.Generator(device="cuda").manual_seed(1234 + spec.K * 10 + spec.R)
+    d_syms = torch.randint(0, 256, (frames * steps * spec.R,), dtype=torch.uint8, device="cuda", generator=g)
+    # a second batch that mixes extremes only: 0 / 255 / 127 / 128
+    pal = torch.tensor([0, 255, 127, 128], dtype=torch.uint8, device="cuda")
+    d_syms2 = pal[torch.randint(0, 4, (frames * steps * spec.R,), device="cuda", generator=g)]
+    variants = [VARIANT_LDS, VARIANT_REGS] if spec.K == 15 else [VARIANT_LDS] + [VARIANT_REGS | ((lb + 1) << 8) for lb in (0, 1, 2)]
+    for syms in (d_syms, d_syms2):
+        results = []
+        for variant in variants:
+            dec = HipViterbi(name, steps, nframes=frames, variant=variant, stream=torch.cuda.current_stream().cuda_stream)
+            out = torch.zeros(frames * (bits // 8), dtype=torch.uint8, device="cuda")
+            dec.reset()
+            dec.update(syms, nbits=steps)
+            dec.chainback(bits, out=out)
+            torch.cuda.synchronize()
+            mets = np.stack([dec.metrics(f) for f in (0, 1, frames // 2, frames - 1)])
+            results.append((out.cpu().numpy().copy(), mets))
+            dec.close()
+        for o, m in results[1:]:
+            assert np.array_equal(o, results[0][0]), "decoded bytes differ between kernel families"
+            assert np.array_equal(m, results[0][1]), "path metrics differ between kernel families"
+        host = syms.cpu().numpy().reshape(frames, steps * spec.R)
+        out0 = results[0][0].reshape(frames, bits // 8)
+        for f in (0, frames - 1):
+            assert np.array_equal(out0[f], oracle_frame(spec, host[f], steps, bits))
