@@ -247,6 +247,18 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        valu = None
+        vpath = os.path.join(ROOT, "profiles", f"valu_{args.code}.json")
+        if os.path.exists(vpath):
+            try:
+                v = json.load(open(vpath))
+                # instructions per launch come from the committed PMC pass; the time is this run's
+                valu = {"wave_instr_per_launch": v["valu_wave_instr_per_launch"],
+                        "achieved_ginstr_per_s": round(v["valu_wave_instr_per_launch"] / (upd_ms * 1e-3) / 1e9, 2),
+                        "issue_ceiling_ginstr_per_s": round(v["issue_ceiling_ginstr_per_s"], 2),
+                        "frac": round(v["valu_wave_instr_per_launch"] / (upd_ms * 1e-3) / 1e9 / v["issue_ceiling_ginstr_per_s"], 4)}
+            except Exception:
+                valu = None
         out = {
             "metric": f"Msymbols/s decoded, K={spec.K} r=1/{spec.R} (init + ACS update + chainback)",
             "value": round(value, 6),
@@ -274,6 +286,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "acs_update", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": abytes},
+            # the binding limit of the K<=15 ACS kernels: packed-integer VALU issue, not HBM
+            "valu_issue": valu,
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, payload_bits, args.cpu_budget)

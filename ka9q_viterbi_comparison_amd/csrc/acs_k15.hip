@@ -81,8 +81,25 @@ __device__ __forceinline__ i16x2 acs(i16x2 lower, i16x2 upper, unsigned &acc) {
     return __builtin_elementwise_min(lower, upper);               // min_epi16
 }
 
-// One trellis step at phase PHI on the 128 positions this thread holds.
-template <int PHI>
+// spiral615 flavour (spiral/spiral615.cpp:220-227): u8 saturating metrics held as (m<<8)|0xff in 16-bit fields so that
+// v_pk_add_u16 clamp == adds_epu8; decision = (min == upper); acc collects the COMPLEMENT at bit KB / 16+KB (KB = 1..8,
+// the min(z, 1<<KB) trick of acs_regs.hip needs z >= 256 whenever it is non-zero).
+template <int KB>
+__device__ __forceinline__ i16x2 acs_u8(i16x2 lower, i16x2 upper, unsigned &acc) {
+    const u16x2 lo = (u16x2)lower, up = (u16x2)upper;
+    const u16x2 z = __builtin_elementwise_sub_sat(up, lo);  // 0 <=> upper <= lower <=> decision 1
+    const u16x2 one = {(unsigned short)(1u << KB), (unsigned short)(1u << KB)};
+    acc |= __builtin_bit_cast(unsigned, __builtin_elementwise_min(z, one));
+    return (i16x2)__builtin_elementwise_min(lo, up);
+}
+template <bool SP>
+__device__ __forceinline__ i16x2 madd(i16x2 a, unsigned t) {
+    if constexpr (SP) return (i16x2)__builtin_elementwise_add_sat((u16x2)a, __builtin_bit_cast(u16x2, t));  // adds_epu8
+    else return __builtin_elementwise_add_sat(a, as_v(t));                                                   // adds_epi16
+}
+
+// One trellis step at phase PHI on the 128 positions this thread holds.  SP selects the spiral615 arithmetic.
+template <bool SP, int PHI>
 __device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R], unsigned tid, unsigned (&words)[4]) {
     constexpr int b = NB - 1 - PHI;            // position bit paired in this phase
     constexpr bool GA = b >= 7;                // group A: free bits 7..13, thread bits 0..6; group B: the reverse
@@ -102,10 +119,16 @@ __device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R],
     for (int r = 0; r < R; r++) s[r] = sraw[r] ^ (((cl >> r) & 1u) ? 255u : 0u);
 
     // t(c) = TA[c & 7] + TB[c >> 3]                                                  viterbi615_sse2.cpp:132-135
+    // spiral615: the terms are ((sym ^ table) >> 2) & 63 (spiral615.cpp:149-215); (s^255)>>2 == 63 - (s>>2)
+    if constexpr (SP) {
+#pragma unroll
+        for (int r = 0; r < R; r++) s[r] >>= 2;
+    }
+    constexpr unsigned FLIP = SP ? 63u : 255u;
     unsigned TA[8], TB[8];
     {
-        const unsigned x0 = s[0] ^ 255u, x1 = s[1] ^ 255u, x2 = s[2] ^ 255u;
-        const unsigned y0 = s[3] ^ 255u, y1 = s[4] ^ 255u, y2 = s[5] ^ 255u;
+        const unsigned x0 = s[0] ^ FLIP, x1 = s[1] ^ FLIP, x2 = s[2] ^ FLIP;
+        const unsigned y0 = s[3] ^ FLIP, y1 = s[4] ^ FLIP, y2 = s[5] ^ FLIP;
         const unsigned a01[4] = {s[0] + s[1], x0 + s[1], s[0] + x1, x0 + x1};
         const unsigned b01[4] = {s[3] + s[4], y0 + s[4], s[3] + y1, y0 + y1};
 #pragma unroll
@@ -114,8 +137,21 @@ __device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R],
             TB[c] = b01[c & 3] + ((c & 4) ? y2 : s[5]);
         }
     }
-    unsigned acc[4] = {0, 0, 0, 0};
-    constexpr unsigned COMP = (unsigned)Code615::bm_comp;
+    unsigned acc[SP ? 8 : 4] = {};
+    constexpr unsigned COMP = SP ? 94u : (unsigned)Code615::bm_comp;
+    // branch-metric fields of a register pair from the table sums (both 16-bit fields at once)
+    auto fields = [&](unsigned sum, unsigned &tp, unsigned &tq) {
+        if constexpr (SP) {
+            // adds_epu8 chain saturates at 255, then (>>2)&63: t = min(63, sum>>2); t' = subs_epu8(94, t)   spiral615.cpp:216-242
+            const u16x2 c63 = {63, 63};
+            const u16x2 t = __builtin_elementwise_min((u16x2)(__builtin_bit_cast(u16x2, sum) >> 2), c63);
+            tp = __builtin_bit_cast(unsigned, (u16x2)(t << 8));
+            tq = (COMP << 8) * 0x10001u - tp;  // 94 - t >= 31 > 0: the saturating subtract never clamps
+        } else {
+            tp = sum;                          // both fields <= 1530: no carry between them
+            tq = COMP * 0x10001u - tp;         // t' = 1530 - t in both fields
+        }
+    };
 
     if constexpr (kf > 0) {
         constexpr int rb = kf - 1;
@@ -131,37 +167,48 @@ __device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R],
             constexpr int r0 = ((i >> rb) << (rb + 1)) | (i & ((1 << rb) - 1));
             constexpr int r1 = r0 | (1 << rb);
             constexpr unsigned cr = cls(rotl14(((unsigned)r0 << 1) << FSH, PHI));
-            const unsigned tp = TAp[cr & 7u] + TBp[cr >> 3];       // both fields <= 1530: no carry between them
-            const unsigned tq = COMP * 0x10001u - tp;              // t' = 1530 - t in both fields
+            unsigned tp, tq;
+            fields(TAp[cr & 7u] + TBp[cr >> 3], tp, tq);
             const i16x2 A = M[r0], B = M[r1];
-            const i16x2 m0 = __builtin_elementwise_add_sat(A, as_v(tp)), m1 = __builtin_elementwise_add_sat(B, as_v(tq));
-            const i16x2 m2 = __builtin_elementwise_add_sat(A, as_v(tq)), m3 = __builtin_elementwise_add_sat(B, as_v(tp));
-            M[r0] = acs<(r0 & 15)>(m0, m1, acc[r0 >> 4]);
-            M[r1] = acs<(r1 & 15)>(m2, m3, acc[r1 >> 4]);
+            const i16x2 m0 = madd<SP>(A, tp), m1 = madd<SP>(B, tq), m2 = madd<SP>(A, tq), m3 = madd<SP>(B, tp);
+            if constexpr (SP) {
+                M[r0] = acs_u8<(r0 & 7) + 1>(m0, m1, acc[r0 >> 3]);
+                M[r1] = acs_u8<(r1 & 7) + 1>(m2, m3, acc[r1 >> 3]);
+            } else {
+                M[r0] = acs<(r0 & 15)>(m0, m1, acc[r0 >> 4]);
+                M[r1] = acs<(r1 & 15)>(m2, m3, acc[r1 >> 4]);
+            }
         });
     } else {
         // half stage: old[j] is the low field, old[j+H] the high field of the same register
         sfor<NR>([&](auto I) {
             constexpr int r0 = decltype(I)::value;
             constexpr unsigned cr = cls(rotl14(((unsigned)r0 << 1) << FSH, PHI));
-            const unsigned t = TA[cr & 7u] + TB[cr >> 3], tc = COMP - t;
+            unsigned tpp, tqq;
+            fields(TA[cr & 7u] + TB[cr >> 3], tpp, tqq);  // low fields: t and t' of this butterfly
+            const unsigned t = tpp & 0xffffu, tc = tqq & 0xffffu;
             const i16x2 A = M[r0];
-            const i16x2 U = __builtin_elementwise_add_sat(A, as_v(t | (tc << 16)));  // (m0, m1)
-            const i16x2 V = __builtin_elementwise_add_sat(A, as_v(tc | (t << 16)));  // (m2, m3)
+            const i16x2 U = madd<SP>(A, t | (tc << 16));  // (m0, m1)
+            const i16x2 V = madd<SP>(A, tc | (t << 16));  // (m2, m3)
             const i16x2 lower = {U.x, V.x}, upper = {U.y, V.y};
-            M[r0] = acs<(r0 & 15)>(lower, upper, acc[r0 >> 4]);
+            if constexpr (SP) M[r0] = acs_u8<(r0 & 7) + 1>(lower, upper, acc[r0 >> 3]);
+            else M[r0] = acs<(r0 & 15)>(lower, upper, acc[r0 >> 4]);
         });
     }
 #pragma unroll
-    for (int w = 0; w < 4; w++) words[w] = ~acc[w];
+    for (int w = 0; w < 4; w++) {
+        if constexpr (SP) words[w] = ~((acc[2 * w] >> 1) | (acc[2 * w + 1] << 7));  // accumulators use bits 1..8 / 17..24
+        else words[w] = ~acc[w];
+    }
 }
 
 struct Smem {
     alignas(16) int16_t img[N];   // 32 KiB: metrics by position
     int flag[2];      // renormalisation request of the current step (double-buffered by row parity)
-    int red[2];       // per-wave minima
+    int red[4];       // per-wave minima (double-buffered by row parity in the spiral flavour)
 };
 
+template <bool SP>
 __global__ __launch_bounds__(THREADS, 2) void acs_k15_kernel(AcsK15Args a) {
     __shared__ Smem sm;
     const unsigned tid = threadIdx.x;
@@ -171,7 +218,7 @@ __global__ __launch_bounds__(THREADS, 2) void acs_k15_kernel(AcsK15Args a) {
     int16_t *gm = a.metrics + f * (long)N;
     for (unsigned p = tid; p < (unsigned)N; p += THREADS) {
         const unsigned st = phi0 == 0 ? p : (((p << phi0) | (p >> (NB - phi0))) & (N - 1u));
-        sm.img[p] = gm[st];
+        sm.img[p] = SP ? (int16_t)(((unsigned)gm[st] << 8) | 0xffu) : gm[st];  // spiral: (m<<8)|0xff fields
     }
     const unsigned char *sp = a.syms + f * (long)a.sym_stride;
     const long lim = (long)a.nsteps * R;
@@ -233,10 +280,29 @@ __global__ __launch_bounds__(THREADS, 2) void acs_k15_kernel(AcsK15Args a) {
                         sraw[q] = (cur[idx >> 2] >> (8 * (idx & 3))) & 255u;
                     }
                     unsigned words[4];
-                    stage<PHI>(M, sraw, tid, words);
+                    stage<SP, PHI>(M, sraw, tid, words);
 #pragma unroll
                     for (int w = 0; w < 4; w++) drow[w * 128] = words[w];
                     drow += 512;
+                    if constexpr (SP) {
+                        // spiral615.cpp:31-40,269: if new[0] > 74 subtract the minimum -- it fires on nearly every step,
+                        // so the workgroup minimum is formed unconditionally behind the one barrier of the step
+                        u16x2 mn = (u16x2)M[0];
+#pragma unroll
+                        for (int i = 1; i < NR; i++) mn = __builtin_elementwise_min(mn, (u16x2)M[i]);
+                        unsigned m = min((unsigned)mn.x, (unsigned)mn.y);
+#pragma unroll
+                        for (int o = 32; o >= 1; o >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, o));
+                        if ((tid & 63u) == 0) sm.red[2 * (r & 1) + (tid >> 6)] = (int)m;
+                        if (tid == 0) sm.flag[r & 1] = (as_u32(M[0]) & 0xffffu) > ((74u << 8) | 0xffu);
+                        __syncthreads();
+                        if (sm.flag[r & 1]) {
+                            const unsigned amt = (unsigned)min(sm.red[2 * (r & 1)], sm.red[2 * (r & 1) + 1]) & 0xff00u;
+                            const u16x2 av = {(unsigned short)amt, (unsigned short)amt};
+#pragma unroll
+                            for (int i = 0; i < NR; i++) M[i] = (i16x2)__builtin_elementwise_sub_sat((u16x2)M[i], av);
+                        }
+                    } else {
                     // renormalise when new[0] >= SHRT_MAX-12750; state 0 is position 0 = thread 0, register 0, low field
                     if (tid == 0) sm.flag[r & 1] = ((int)(short)(as_u32(M[0]) & 0xffffu)) >= Code615::renorm_thr;
                     __syncthreads();
@@ -254,6 +320,7 @@ __global__ __launch_bounds__(THREADS, 2) void acs_k15_kernel(AcsK15Args a) {
                         const u16x2 av = {(unsigned short)adj, (unsigned short)adj};
 #pragma unroll
                         for (int i = 0; i < NR; i++) M[i] = (i16x2)((u16x2)M[i] - av);  // sub_epi16 wraps   :181-182
+                    }
                     }
                 }
             });
@@ -279,7 +346,7 @@ __global__ __launch_bounds__(THREADS, 2) void acs_k15_kernel(AcsK15Args a) {
     const int phie = row_end % NB;
     for (unsigned p = tid; p < (unsigned)N; p += THREADS) {
         const unsigned st = phie == 0 ? p : (((p << phie) | (p >> (NB - phie))) & (N - 1u));
-        gm[st] = sm.img[p];
+        gm[st] = SP ? (int16_t)(((unsigned)(unsigned short)sm.img[p]) >> 8) : sm.img[p];
     }
 }
 
@@ -318,8 +385,9 @@ bool k15_poly_supported(const int *poly) {
     return true;
 }
 
-hipError_t launch_acs_k15(const AcsK15Args &a, hipStream_t stream) {
-    hipLaunchKernelGGL(k15::acs_k15_kernel, dim3(a.nframes), dim3(k15::THREADS), 0, stream, a);
+hipError_t launch_acs_k15(const AcsK15Args &a, bool spiral, hipStream_t stream) {
+    if (spiral) hipLaunchKernelGGL(k15::acs_k15_kernel<true>, dim3(a.nframes), dim3(k15::THREADS), 0, stream, a);
+    else hipLaunchKernelGGL(k15::acs_k15_kernel<false>, dim3(a.nframes), dim3(k15::THREADS), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -63,7 +63,7 @@ struct AcsK15Args {
 };
 struct ChainbackRowsArgs;
 bool k15_poly_supported(const int *poly);
-hipError_t launch_acs_k15(const AcsK15Args &a, hipStream_t stream);
+hipError_t launch_acs_k15(const AcsK15Args &a, bool spiral, hipStream_t stream);  // spiral: the spiral615 arithmetic
 hipError_t launch_chainback_k15(const ChainbackRowsArgs &a, hipStream_t stream);
 
 // ---------------------------------------------------------------- chainback.hip (natural rows)

@@ -134,13 +134,13 @@ int auto_regs_lb(int code, int nframes) {
 int auto_variant(const vhip_decoder *p) {
     if (p->code == VHIP_KA9Q224) return vh::k24f_poly_supported(p->poly) ? VHIP_VARIANT_HBM_FUSED : VHIP_VARIANT_HBM;
     if (p->K <= 9 && vh::regs_poly_supported(p->code, p->poly)) return VHIP_VARIANT_REGS;
-    if (p->code == VHIP_KA9Q615 && vh::k15_poly_supported(p->poly)) return VHIP_VARIANT_REGS;
+    if ((p->code == VHIP_KA9Q615 || p->code == VHIP_SPIRAL615) && vh::k15_poly_supported(p->poly)) return VHIP_VARIANT_REGS;
     return VHIP_VARIANT_LDS;
 }
 
 void apply_variant(vhip_decoder *p, int variant, int lb) {
     p->variant = variant;
-    if (variant == VHIP_VARIANT_REGS && p->code != VHIP_KA9Q615) {
+    if (variant == VHIP_VARIANT_REGS && p->K != 15) {
         p->regs_lb = lb;
         p->lay = vh::regs_layout(p->code, lb);
     }
@@ -348,7 +348,7 @@ int vhip_set_variant(vhip_decoder *p, int variant) {
         if (variant != VHIP_VARIANT_HBM && variant != VHIP_VARIANT_HBM_FUSED) return fail("set_variant: K=24 supports only the HBM variants");
         if (variant == VHIP_VARIANT_HBM_FUSED && !vh::k24f_poly_supported(p->poly))
             return fail("set_variant: the fused K=24 kernel needs the harness polynomials");
-    } else if (variant == VHIP_VARIANT_REGS && p->code == VHIP_KA9Q615) {
+    } else if (variant == VHIP_VARIANT_REGS && p->K == 15) {
         if (!vh::k15_poly_supported(p->poly)) return fail("set_variant: the K=15 register kernel needs the harness polynomials");
     } else if (variant == VHIP_VARIANT_REGS) {
         if (p->K > 9 || !vh::regs_poly_supported(p->code, p->poly))
@@ -401,7 +401,7 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
                                                                 : k24_update_frame(p, f, d_syms + (size_t)f * sym_stride, steps, row0);
             if (rc != 0) return -1;
         }
-    } else if (p->variant == VHIP_VARIANT_REGS && p->code == VHIP_KA9Q615) {
+    } else if (p->variant == VHIP_VARIANT_REGS && p->K == 15) {
         vh::AcsK15Args a;
         a.syms = d_syms;
         a.sym_stride = sym_stride;
@@ -411,7 +411,7 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
         a.nframes = p->nframes;
         a.dec = p->d_dec;
         a.metrics = p->d_metrics;
-        HIP_TRY(vh::launch_acs_k15(a, p->stream));
+        HIP_TRY(vh::launch_acs_k15(a, p->code == VHIP_SPIRAL615, p->stream));
     } else if (p->variant == VHIP_VARIANT_REGS) {
         vh::AcsRegsArgs a;
         a.syms = d_syms;
@@ -460,7 +460,7 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
         else HIP_TRY(vh::launch_chainback_spec(vh::CB_LAY_K24F, a, p->stream));
         return 0;
     }
-    if (p->variant == VHIP_VARIANT_REGS && p->code == VHIP_KA9Q615) {
+    if (p->variant == VHIP_VARIANT_REGS && p->K == 15) {
         vh::ChainbackRowsArgs a;
         a.dec = p->d_dec;
         a.cap_rows = p->cap_rows;
@@ -565,7 +565,7 @@ int vhip_read_decision_rows(vhip_decoder *p, int frame, int row0, int nrows, uns
         }
         return 0;
     }
-    if (p->variant == VHIP_VARIANT_REGS && p->code == VHIP_KA9Q615) {
+    if (p->variant == VHIP_VARIANT_REGS && p->K == 15) {
         // [row][word][thread] of acs_k15.hip -> natural bitmap
         const int NB = 14;
         std::vector<unsigned> raw((size_t)nrows * 512);

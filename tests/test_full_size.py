@@ -109,7 +109,7 @@ def test_sweep_codes_roundtrip(name, frames):
     assert sums[0] == sums[1]
 
 
-@pytest.mark.parametrize("name", ["27", "47", "29", "49", "spiral27", "spiral29", "615"])
+@pytest.mark.parametrize("name", ["27", "47", "29", "49", "spiral27", "spiral29", "615", "spiral615"])
 def test_pure_noise_cross_kernel_stress(name):
     """Uniform random symbols (no codeword underneath) drive the path metrics to their widest spread -- the regime of
     wrap-around / saturation / tie corner cases.  Large batches, every kernel family: decoded bytes and final path

@@ -67,7 +67,7 @@ def test_hip_reproduces_golden(code):
     steps, nrows, B = int(g["steps"]), int(g["nrows"]), int(g["payload_bytes"])
     variants = [0]
     if int(g["K"]) == 15:
-        variants = [1, 2] if code == C.KA9Q615 else [1]
+        variants = [1, 2]
     if int(g["K"]) == 24:
         variants = [3, 4]
     if int(g["K"]) <= 9:

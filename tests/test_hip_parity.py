@@ -24,7 +24,7 @@ def variants_for(code):
     if code == C.KA9Q615:
         return [VARIANT_LDS, VARIANT_REGS]
     if code == C.SPIRAL615:
-        return [VARIANT_LDS]
+        return [VARIANT_LDS, VARIANT_REGS]
     if code in (C.KA9Q27, C.SPIRAL47, C.SPIRAL27):
         return [VARIANT_LDS, regs(0), regs(1), regs(2)]
     return [VARIANT_LDS, regs(0), regs(1), regs(2)]
