@@ -15,7 +15,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r01_sweep"))
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--cpu", action="store_true", help="also time the CPU baseline per code (adds ~12 s each)")
-    ap.add_argument("--codes", default="27,47,29,49,615,224,spiral27,spiral29")
+    ap.add_argument("--codes", default="27,47,29,49,615,224,spiral27,spiral29,spiral615")
     args = ap.parse_args()
     lines = []
     for code in args.codes.split(","):
