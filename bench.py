@@ -206,16 +206,30 @@ def main():
     # HBM-bound chainback of one batch overlaps the VALU-bound update of the next (steady-state serving throughput).
     pipelined = None
     if args.pipeline and spec.K <= 15 and nchunks == 1:
-        s2 = torch.cuda.Stream(device=dev)
-        dec2 = HipViterbi(args.code, nsteps, nframes=frames, variant=args.variant, stream=s2.cuda_stream)
+        # Two handles (two decision-history buffers).  All ACS updates go, in order, to one high-priority stream, so
+        # the next update is dispatched first and spreads evenly over the CUs (exactly one wave per SIMD: a
+        # chainback workgroup that got there first would make two update workgroups share a CU and double their
+        # time); every chainback goes to a normal-priority stream behind an event and fills in beside the next update.
+        hi = torch.cuda.Stream(device=dev, priority=-1)
+        lo = torch.cuda.Stream(device=dev, priority=0)
+        dec2 = HipViterbi(args.code, nsteps, nframes=frames, variant=args.variant, stream=hi.cuda_stream)
         d_out2 = torch.zeros_like(d_out)
-        lanes = [(dec, stream, d_out), (dec2, s2, d_out2)]
+        lanes = [(dec, d_out), (dec2, d_out2)]
+        cb_done = [None, None]
+        torch.cuda.synchronize()
 
         def pass_on(k):
-            dk, sk, ok = lanes[k & 1]
+            dk, ok = lanes[k & 1]
+            if cb_done[k & 1] is not None:
+                hi.wait_event(cb_done[k & 1])  # this handle's previous history has been walked
+            dk.set_stream(hi.cuda_stream)
             dk.reset()
             dk.update(d_syms, nbits=nsteps)
+            upd_done = hi.record_event()
+            lo.wait_event(upd_done)
+            dk.set_stream(lo.cuda_stream)
             dk.chainback(cb_bits, out=ok)
+            cb_done[k & 1] = lo.record_event()
 
         for k in range(2):
             pass_on(k)
@@ -226,6 +240,7 @@ def main():
         barrier()
         pipelined = max_over_ranks(time.perf_counter() - t0, dev)
         assert torch.equal(d_out, d_out2)
+        dec.set_stream(stream.cuda_stream)
         dec2.close()
 
     upd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))

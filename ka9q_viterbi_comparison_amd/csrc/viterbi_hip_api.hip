@@ -72,6 +72,8 @@ struct vhip_decoder {
     vh::RegsLayout lay{};      // REGS variant: decision layout
     int frames_padded = 0;     // frames rounded up to a whole wave (both decision layouts fit the same buffer)
     hipStream_t aux_stream[2] = {nullptr, nullptr};  // K=24 with several frames: two decodes in flight
+    int *h_pending = nullptr;                        // K=24: pinned copies of the renormalisation flag, [3 streams][2 batches]
+    hipEvent_t k24_ev[3][2] = {};                    // K=24: "batch finished and its flag copy landed"
     size_t total_bytes = 0;
 };
 
@@ -198,41 +200,73 @@ int k24f_update_frame(vhip_decoder *p, int f, const unsigned char *d_syms, int s
                                      d_syms + ((long)q.rel - q.s_lo) * 2, q.rel - q.s_lo, q.s_lo, q.s_hi, flags, stream));
         return 0;
     };
-    constexpr int BATCH = 24;  // passes between flag checks
-    int t = 0;                 // next row of this call
+    // Speculative renormalisation: passes are issued in batches, each followed by an asynchronous copy
+    // of the sticky flag into pinned memory.  Two batches are kept in flight, so the device already runs batch b+1
+    // while the host looks at the flag of batch b; a batch whose flag is clear is committed.  When a flag is raised
+    // every later pass has returned at once (it sees a flag of an earlier row), the stream is drained, the raising
+    // pass is replayed up to the flagged row, the metrics are renormalised and the pipeline restarts behind that row.
+    constexpr int BATCH = 12;
+    const int slot = (int)((flags - p->d_flags) / 4);  // 0: handle stream, 1/2: the two worker streams
+    struct Batch { std::vector<Pass> passes; int t_end = 0, cur_end = 0; };
+    int t = 0;  // next row of this call
     while (t < steps) {
-        std::vector<Pass> batch;
+        Batch q[2];
         int tt = t, c = cur;
-        while (tt < steps && (int)batch.size() < BATCH) {
-            const int phi = (row0 + tt) % 23;
-            int first, np;
-            const int g = group_of(phi, first, np);
-            Pass q{g, phi - first, std::min(np, phi - first + (steps - tt)), tt, c};
-            if (launch(q) != 0) return -1;
-            batch.push_back(q);
-            tt += q.s_hi - q.s_lo;
-            c ^= 1;
+        auto enqueue = [&](int k) -> int {
+            Batch &b = q[k];
+            b.passes.clear();
+            while (tt < steps && (int)b.passes.size() < BATCH) {
+                const int phi = (row0 + tt) % 23;
+                int first, np;
+                const int g = group_of(phi, first, np);
+                Pass ps{g, phi - first, std::min(np, phi - first + (steps - tt)), tt, c};
+                if (launch(ps) != 0) return -1;
+                b.passes.push_back(ps);
+                tt += ps.s_hi - ps.s_lo;
+                c ^= 1;
+            }
+            b.t_end = tt;
+            b.cur_end = c;
+            HIP_TRY(hipMemcpyAsync(p->h_pending + slot * 2 + k, flags + vh::K24F_PENDING, sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipEventRecord(p->k24_ev[slot][k], stream));
+            return 0;
+        };
+        int inflight = 0, k = 0;
+        if (enqueue(0) != 0) return -1;
+        inflight++;
+        if (tt < steps) {
+            if (enqueue(1) != 0) return -1;
+            inflight++;
         }
-        int pending = 0;
-        HIP_TRY(hipMemcpyAsync(&pending, flags + vh::K24F_PENDING, sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        if (pending == 0) {
-            t = tt;
-            cur = c;
-            continue;
+        while (inflight > 0) {
+            HIP_TRY(hipEventSynchronize(p->k24_ev[slot][k]));
+            const int pending = p->h_pending[slot * 2 + k];
+            if (pending == 0) {
+                t = q[k].t_end;
+                cur = q[k].cur_end;
+                inflight--;
+                if (tt < steps) {
+                    if (enqueue(k) != 0) return -1;
+                    inflight++;
+                }
+                k ^= 1;
+                continue;
+            }
+            HIP_TRY(hipStreamSynchronize(stream));  // the younger batch only holds passes that returned at once
+            const int rr = pending - 1;             // renormalise after this row of the call
+            const Pass *hit = nullptr;
+            for (const Pass &ps : q[k].passes)
+                if (rr >= ps.rel && rr < ps.rel + (ps.s_hi - ps.s_lo)) hit = &ps;
+            if (!hit) return fail("K=24 fused: renormalisation flag out of range");
+            HIP_TRY(vh::launch_k24_flags_reset(flags, stream));
+            Pass redo = *hit;
+            redo.s_hi = redo.s_lo + (rr - redo.rel) + 1;  // replay the raising pass up to and including row rr
+            if (launch(redo) != 0) return -1;
+            cur = redo.in ^ 1;
+            HIP_TRY(vh::launch_k24_renorm(buf[cur], flags, stream));  // min-reduce, wrapping subtract, clear flags
+            t = rr + 1;
+            break;  // restart the pipeline behind the renormalised row
         }
-        const int rr = pending - 1;  // renormalise after this row of the call
-        const Pass *hit = nullptr;
-        for (const Pass &q : batch)
-            if (rr >= q.rel && rr < q.rel + (q.s_hi - q.s_lo)) hit = &q;
-        if (!hit) return fail("K=24 fused: renormalisation flag out of range");
-        HIP_TRY(vh::launch_k24_flags_reset(flags, stream));
-        Pass redo = *hit;
-        redo.s_hi = redo.s_lo + (rr - redo.rel) + 1;  // replay the raising pass up to and including row rr
-        if (launch(redo) != 0) return -1;
-        cur = redo.in ^ 1;
-        HIP_TRY(vh::launch_k24_renorm(buf[cur], flags, stream));  // min-reduce, wrapping subtract, clear flags
-        t = rr + 1;
     }
     p->k24_cur[f] = cur;
     return 0;
@@ -303,6 +337,10 @@ vhip_decoder *vhip_create(int code, const int *poly, int len, int nframes) {
     }
     if (code == VHIP_KA9Q224 && nframes > 1)
         for (int w = 0; w < 2 && e == hipSuccess; w++) e = hipStreamCreateWithFlags(&p->aux_stream[w], hipStreamNonBlocking);
+    if (code == VHIP_KA9Q224) {
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&p->h_pending), sizeof(int) * 6, hipHostMallocDefault);
+        for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&p->k24_ev[i / 2][i % 2], hipEventDisableTiming);
+    }
     if (e != hipSuccess) {
         fail("create: stream", e);
         vhip_delete(p);
@@ -330,6 +368,9 @@ void vhip_delete(vhip_decoder *p) {
     if (p->d_flags) (void)hipFree(p->d_flags);
     for (int w = 0; w < 2; w++)
         if (p->aux_stream[w]) (void)hipStreamDestroy(p->aux_stream[w]);
+    for (int i = 0; i < 6; i++)
+        if (p->k24_ev[i / 2][i % 2]) (void)hipEventDestroy(p->k24_ev[i / 2][i % 2]);
+    if (p->h_pending) (void)hipHostFree(p->h_pending);
     if (p->d_syms_stage) (void)hipFree(p->d_syms_stage);
     if (p->d_data_stage) (void)hipFree(p->d_data_stage);
     delete p;
