@@ -69,7 +69,7 @@ __device__ __forceinline__ i16x2 as_v(unsigned x) { return __builtin_bit_cast(i1
 constexpr int group_first_phase(int g) { return g < 4 ? 4 * g : 16; }
 constexpr int group_nphases(int g) { return g < 4 ? 4 : 7; }
 constexpr int group_bshift(int g) { return k24f_bshift(g); }
-constexpr int group_vw(int g) { return k24f_vw(g); }          // 4 (8-byte vectors) for the strided groups, 8 for group 4
+constexpr int group_vw(int g) { return k24f_vw(g); }          // 2 or 4 for the strided groups, 8 for group 4
 constexpr int group_nr(int g) { return 16 * group_vw(g) / 2; }  // packed registers per thread
 
 // packed ACS, tie -> lower (cmpgt_epi16 then min_epi16, viterbi224_sse2.cpp:190-194); acc gets the decision bits
@@ -87,7 +87,7 @@ __device__ __forceinline__ i16x2 acs(i16x2 lower, i16x2 upper, unsigned &acc) {
 template <int G, int PHI>
 __device__ __forceinline__ void stage(i16x2 (&M)[group_nr(G)], unsigned s0, unsigned s1, unsigned pt, unsigned (&acc)[group_nr(G) / 16]) {
     constexpr int b = NB - 1 - PHI;
-    constexpr int BS = group_bshift(G), NR = group_nr(G), KB = group_vw(G) == 8 ? 2 : 1;
+    constexpr int BS = group_bshift(G), NR = group_nr(G), KB = k24f_lw(G) - 1;
     // static position of register rho, low field
     auto spos = [](int rho) constexpr -> unsigned {
         return ((unsigned)(rho >> KB) << BS) | ((unsigned)(rho & ((1 << KB) - 1)) << 1);
@@ -140,19 +140,30 @@ __device__ __forceinline__ void stage(i16x2 (&M)[group_nr(G)], unsigned s0, unsi
     }
 }
 
-template <int G>
-__global__ __launch_bounds__(256) void acs_k24f_pass_kernel(const int16_t *__restrict__ oldm, int16_t *__restrict__ newm,
-                                                            unsigned char *__restrict__ rows, const unsigned char *__restrict__ syms,
-                                                            int rel_row0, int s_lo, int s_hi, int *__restrict__ flags) {
+// FULL: every stage of the group runs (s_lo == 0, s_hi == NP) -- the steady state.  The stage branches then vanish and
+// hipcc can see that nothing but row stores is outstanding after the first stage, so no later s_waitcnt drains them.
+template <int G, bool FULL>
+__global__ __launch_bounds__(256) void acs_k24f_pass_kernel(const int16_t *oldm, int16_t *__restrict__ newm,
+                                                            unsigned char *__restrict__ rows, const unsigned char *syms,
+                                                            int rel_row0, int s_lo, int s_hi, int *__restrict__ flags,
+                                                            int *__restrict__ mirror) {
     // rows/syms point at the first row of THIS pass's phase 0 of the group; rel_row0 = that row's index in the call.
     // Stages s in [s_lo, s_hi) of the group run; a pending renormalisation of an earlier row cancels the pass.
-    const int pending = flags[K24F_PENDING];
-    if (pending != 0 && pending - 1 < rel_row0 + s_lo) return;
+    int pending = flags[K24F_PENDING];  // looked at below, behind the metric loads
     constexpr int BS = group_bshift(G), P0 = group_first_phase(G), NP = group_nphases(G);
     constexpr int NR = group_nr(G), WPT = NR / 16;
     const unsigned u = blockIdx.x * blockDim.x + threadIdx.x;  // N / (16*VW) threads
     const unsigned pt = k24f_thread_base(G, u);                // thread part of the position
     i16x2 M[NR];
+    // Every symbol of the pass is fetched here, next to the metric loads: a fetch at the top of each stage would put a
+    // full memory round trip (and, through vmcnt(0), the acknowledgement of the previous row store) on the critical
+    // path of every trellis step.  Indices are clamped to the stages that run, so a truncated pass reads nothing else.
+    unsigned sy[NP];
+#pragma unroll
+    for (int S = 0; S < NP; S++) {
+        const int sc = FULL ? S : min(max(S, s_lo), s_hi - 1);
+        sy[S] = (unsigned)syms[2 * sc] | ((unsigned)syms[2 * sc + 1] << 8);
+    }
     // Group 4 holds 16 CONTIGUOUS vectors per thread (256 B), so a direct load would touch 64 separate 256-byte
     // chunks per wave instruction.  Instead each wave streams its 16 KiB tile in lane-linear order (1 KiB per
     // instruction) and transposes it through a wave-private, XOR-swizzled LDS tile (conflict-free both ways).
@@ -179,27 +190,42 @@ __global__ __launch_bounds__(256) void acs_k24f_pass_kernel(const int16_t *__res
     } else {
 #pragma unroll
         for (int v = 0; v < 16; v++) {
-            const uint2 q = *reinterpret_cast<const uint2 *>(oldm + (pt | ((unsigned)v << BS)));
-            M[2 * v] = as_v(q.x);
-            M[2 * v + 1] = as_v(q.y);
+            if constexpr (group_vw(G) == 4) {
+                const uint2 q = *reinterpret_cast<const uint2 *>(oldm + (pt | ((unsigned)v << BS)));
+                M[2 * v] = as_v(q.x);
+                M[2 * v + 1] = as_v(q.y);
+            } else {
+                M[v] = as_v(*reinterpret_cast<const unsigned *>(oldm + (pt | ((unsigned)v << BS))));
+            }
         }
+    }
+    // The flag is a dependent scalar load: looking at it only here keeps its latency under the metric loads.  The empty
+    // asm pins that order (hipcc otherwise sinks the loads below the branch, or hoists the compare above them), which
+    // is also why oldm and syms are not __restrict__.
+    asm volatile("" : "+s"(pending) : : "memory");
+    if (pending != 0 && pending - 1 < rel_row0 + s_lo) {
+        if (mirror && blockIdx.x == 0 && threadIdx.x == 0) *mirror = pending;
+        return;
     }
     sfor<NP>([&](auto I) {
         constexpr int S = decltype(I)::value;
         constexpr int PHI = P0 + S;
-        if (S >= s_lo && S < s_hi) {  // grid-uniform
-            const unsigned sy0 = syms[2 * S], sy1 = syms[2 * S + 1];
+        if (FULL || (S >= s_lo && S < s_hi)) {  // grid-uniform
+            const unsigned sy0 = sy[S] & 255u, sy1 = sy[S] >> 8;
             unsigned acc[WPT];
             stage<G, PHI>(M, sy0, sy1, pt, acc);
             unsigned *row = reinterpret_cast<unsigned *>(rows + (size_t)S * (N / 8)) + (size_t)u * WPT;
             if constexpr (WPT == 4) *reinterpret_cast<uint4 *>(row) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
-            else *reinterpret_cast<uint2 *>(row) = make_uint2(acc[0], acc[1]);
+            else if constexpr (WPT == 2) *reinterpret_cast<uint2 *>(row) = make_uint2(acc[0], acc[1]);
+            else *row = acc[0];
             if (u == 0) {  // state 0 is position 0 in every phase: thread 0, register 0, low field
                 const int new0 = (int)(short)(as_u32(M[0]) & 0xffffu);
-                if (new0 >= Code224::renorm_thr && flags[K24F_PENDING] == 0) flags[K24F_PENDING] = rel_row0 + S + 1;
+                if (new0 >= Code224::renorm_thr && pending == 0) flags[K24F_PENDING] = pending = rel_row0 + S + 1;
             }
         }
     });
+    // the last pass of a host batch also reports the flag to pinned host memory (thread 0 is the only writer of the flag)
+    if (mirror && u == 0) *mirror = pending;
     if constexpr (G == 4) {
         uint4 *tw = tile + wv * 1024;
 #pragma unroll
@@ -214,8 +240,12 @@ __global__ __launch_bounds__(256) void acs_k24f_pass_kernel(const int16_t *__res
         }
     } else {
 #pragma unroll
-        for (int v = 0; v < 16; v++)
-            *reinterpret_cast<uint2 *>(newm + (pt | ((unsigned)v << BS))) = make_uint2(as_u32(M[2 * v]), as_u32(M[2 * v + 1]));
+        for (int v = 0; v < 16; v++) {
+            if constexpr (group_vw(G) == 4)
+                *reinterpret_cast<uint2 *>(newm + (pt | ((unsigned)v << BS))) = make_uint2(as_u32(M[2 * v]), as_u32(M[2 * v + 1]));
+            else
+                *reinterpret_cast<unsigned *>(newm + (pt | ((unsigned)v << BS))) = as_u32(M[v]);
+        }
     }
 }
 
@@ -250,15 +280,31 @@ bool k24f_poly_supported(const int *poly) { return poly[0] == k24f::POLY[0] && p
 
 // one pass: stages [s_lo, s_hi) of group g; rows/syms are those of the group's first phase
 hipError_t launch_k24f_pass(int g, const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,
-                            int rel_row0, int s_lo, int s_hi, int *flags, hipStream_t stream) {
+                            int rel_row0, int s_lo, int s_hi, int *flags, int *mirror, hipStream_t stream) {
     const dim3 block(256);
-    const dim3 grid(g < 4 ? 131072 / 256 : 65536 / 256);  // 64 positions per thread in groups 0-3, 128 in group 4
+    const dim3 grid((k24f::N / (16u * (unsigned)k24f_vw(g))) / 256u);  // 16 vectors of VW positions per thread
+    const bool full = s_lo == 0 && s_hi == (g < 4 ? 4 : 7);
     switch (g) {
-    case 0: hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<0>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags); break;
-    case 1: hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<1>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags); break;
-    case 2: hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<2>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags); break;
-    case 3: hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<3>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags); break;
-    case 4: hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<4>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags); break;
+    case 0:
+        if (full) hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<0, true>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);
+        else hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<0, false>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);
+        break;
+    case 1:
+        if (full) hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<1, true>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);
+        else hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<1, false>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);
+        break;
+    case 2:
+        if (full) hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<2, true>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);
+        else hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<2, false>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);
+        break;
+    case 3:
+        if (full) hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<3, true>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);
+        else hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<3, false>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);
+        break;
+    case 4:
+        if (full) hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<4, true>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);
+        else hipLaunchKernelGGL((k24f::acs_k24f_pass_kernel<4, false>), grid, block, 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);
+        break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -16,11 +16,15 @@ namespace vh {
 
 K24F_HD constexpr int k24f_group_of_phase(int phi) { return phi < 16 ? phi / 4 : 4; }
 K24F_HD constexpr int k24f_bshift(int g) { return g < 4 ? 19 - 4 * g : 3; }  // lowest vector-index position bit
-K24F_HD constexpr int k24f_vw(int g) { return g < 4 ? 4 : 8; }               // positions per vector
+// log2(positions per vector): the strided groups keep K24F_LWS (1 -> 32 positions, 16 packed registers per thread,
+// four waves per SIMD; 2 -> 64 positions, two waves per SIMD), group 4 keeps 8 contiguous positions per vector
+constexpr int K24F_LWS = 1;
+K24F_HD constexpr int k24f_lw(int g) { return g < 4 ? K24F_LWS : 3; }
+K24F_HD constexpr int k24f_vw(int g) { return 1 << k24f_lw(g); }             // positions per vector
 
 // thread part of the position for thread u of group g (vector-index and in-vector bits zero)
 K24F_HD unsigned k24f_thread_base(int g, unsigned u) {
-    const int BS = k24f_bshift(g), LW = g < 4 ? 2 : 3;  // log2(VW)
+    const int BS = k24f_bshift(g), LW = k24f_lw(g);
     const unsigned ulo = u & ((1u << (BS - LW)) - 1u), uhi = u >> (BS - LW);
     return (uhi << (BS + 4)) | (ulo << LW);
 }
@@ -28,7 +32,7 @@ K24F_HD unsigned k24f_thread_base(int g, unsigned u) {
 // position p at phase phi -> 32-bit word index inside the 1 MiB row, bit inside the word
 K24F_HD void k24f_locate(unsigned p, int phi, unsigned &word, unsigned &bit) {
     const int g = k24f_group_of_phase(phi);
-    const int BS = k24f_bshift(g), LW = g < 4 ? 2 : 3, KB = LW - 1;
+    const int BS = k24f_bshift(g), LW = k24f_lw(g), KB = LW - 1;
     const unsigned h = p & 1u, k = (p >> 1) & ((1u << KB) - 1u), v = (p >> BS) & 15u;
     const unsigned ulo = (p >> LW) & ((1u << (BS - LW)) - 1u), uhi = p >> (BS + 4);
     const unsigned u = (uhi << (BS - LW)) | ulo;

@@ -91,7 +91,7 @@ hipError_t launch_k24_flags_reset(int *flags, hipStream_t stream);
 // ---------------------------------------------------------------- acs_k24f.hip (K = 24, 4/7 steps per pass)
 bool k24f_poly_supported(const int *poly);
 hipError_t launch_k24f_pass(int g, const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,
-                            int rel_row0, int s_lo, int s_hi, int *flags, hipStream_t stream);
+                            int rel_row0, int s_lo, int s_hi, int *flags, int *mirror, hipStream_t stream);
 hipError_t launch_chainback_k24f(const ChainbackRowsArgs &a, hipStream_t stream);
 
 // ---------------------------------------------------------------- chainback_spec.hip (K = 15 / 24, one wave per frame)

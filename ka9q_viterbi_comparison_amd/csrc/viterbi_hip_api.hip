@@ -73,6 +73,7 @@ struct vhip_decoder {
     int frames_padded = 0;     // frames rounded up to a whole wave (both decision layouts fit the same buffer)
     hipStream_t aux_stream[2] = {nullptr, nullptr};  // K=24 with several frames: two decodes in flight
     int *h_pending = nullptr;                        // K=24: pinned copies of the renormalisation flag, [3 streams][2 batches]
+    int *h_pending_dev = nullptr;                    //        the same words as the device addresses them
     hipEvent_t k24_ev[3][2] = {};                    // K=24: "batch finished and its flag copy landed"
     size_t total_bytes = 0;
 };
@@ -194,10 +195,10 @@ int k24f_update_frame(vhip_decoder *p, int f, const unsigned char *d_syms, int s
         if (phi < 16) { first = (phi / 4) * 4; np = 4; return phi / 4; }
         first = 16; np = 7; return 4;
     };
-    auto launch = [&](const Pass &q) -> int {
+    auto launch = [&](const Pass &q, int *mirror) -> int {
         const long row_g0 = (long)row0 + q.rel - q.s_lo;  // absolute row of the group's phase 0 (may precede row0)
         HIP_TRY(vh::launch_k24f_pass(q.g, buf[q.in], buf[q.in ^ 1], rows + row_g0 * (long)p->row_bytes,
-                                     d_syms + ((long)q.rel - q.s_lo) * 2, q.rel - q.s_lo, q.s_lo, q.s_hi, flags, stream));
+                                     d_syms + ((long)q.rel - q.s_lo) * 2, q.rel - q.s_lo, q.s_lo, q.s_hi, flags, mirror, stream));
         return 0;
     };
     // Speculative renormalisation: passes are issued in batches, each followed by an asynchronous copy
@@ -220,14 +221,16 @@ int k24f_update_frame(vhip_decoder *p, int f, const unsigned char *d_syms, int s
                 int first, np;
                 const int g = group_of(phi, first, np);
                 Pass ps{g, phi - first, std::min(np, phi - first + (steps - tt)), tt, c};
-                if (launch(ps) != 0) return -1;
+                const int adv = ps.s_hi - ps.s_lo;
+                const bool last = tt + adv >= steps || (int)b.passes.size() + 1 == BATCH;
+                // the last pass of the batch reports the flag word straight into pinned host memory
+                if (launch(ps, last ? p->h_pending_dev + slot * 2 + k : nullptr) != 0) return -1;
                 b.passes.push_back(ps);
-                tt += ps.s_hi - ps.s_lo;
+                tt += adv;
                 c ^= 1;
             }
             b.t_end = tt;
             b.cur_end = c;
-            HIP_TRY(hipMemcpyAsync(p->h_pending + slot * 2 + k, flags + vh::K24F_PENDING, sizeof(int), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipEventRecord(p->k24_ev[slot][k], stream));
             return 0;
         };
@@ -261,7 +264,7 @@ int k24f_update_frame(vhip_decoder *p, int f, const unsigned char *d_syms, int s
             HIP_TRY(vh::launch_k24_flags_reset(flags, stream));
             Pass redo = *hit;
             redo.s_hi = redo.s_lo + (rr - redo.rel) + 1;  // replay the raising pass up to and including row rr
-            if (launch(redo) != 0) return -1;
+            if (launch(redo, nullptr) != 0) return -1;
             cur = redo.in ^ 1;
             HIP_TRY(vh::launch_k24_renorm(buf[cur], flags, stream));  // min-reduce, wrapping subtract, clear flags
             t = rr + 1;
@@ -338,7 +341,8 @@ vhip_decoder *vhip_create(int code, const int *poly, int len, int nframes) {
     if (code == VHIP_KA9Q224 && nframes > 1)
         for (int w = 0; w < 2 && e == hipSuccess; w++) e = hipStreamCreateWithFlags(&p->aux_stream[w], hipStreamNonBlocking);
     if (code == VHIP_KA9Q224) {
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&p->h_pending), sizeof(int) * 6, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&p->h_pending), sizeof(int) * 6, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_pending_dev), p->h_pending, 0);
         for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&p->k24_ev[i / 2][i % 2], hipEventDisableTiming);
     }
     if (e != hipSuccess) {
