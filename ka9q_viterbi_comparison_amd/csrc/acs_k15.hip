@@ -27,6 +27,7 @@
 #include <type_traits>
 #include <utility>
 
+#include "k15_layout.h"
 #include "kernels.h"
 #include "viterbi_codes.h"
 
@@ -71,14 +72,21 @@ constexpr unsigned cls(unsigned j) {
 __device__ __forceinline__ unsigned as_u32(i16x2 x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ i16x2 as_v(unsigned x) { return __builtin_bit_cast(i16x2, x); }
 
-// packed ACS for two new states; acc collects the COMPLEMENT of the decision at bit KB / 16+KB
-template <int KB>
-__device__ __forceinline__ i16x2 acs(i16x2 lower, i16x2 upper, unsigned &acc) {
-    const i16x2 w = __builtin_elementwise_sub_sat(lower, upper);  // < 0  <=>  lower < upper  <=>  decision 0
-    const i16x2 full = w >> 15;                                   // 0xffff where decision is 0
-    constexpr unsigned mask = (1u << KB) | (1u << (16 + KB));
-    acc = (as_u32(full) & mask) | (acc & ~mask);                  // v_bfi_b32
-    return __builtin_elementwise_min(lower, upper);               // min_epi16
+// packed ACS for two new states (ka9q615): w < 0  <=>  lower < upper  <=>  decision 0 (tie -> upper, viterbi615_sse2.cpp:145-148)
+__device__ __forceinline__ i16x2 acs(i16x2 lower, i16x2 upper, i16x2 &w) {
+    w = __builtin_elementwise_sub_sat(lower, upper);
+    return __builtin_elementwise_min(lower, upper);  // min_epi16
+}
+// Decision bits of the register pair (RE, RE+1), RE even: one v_perm_b32 gathers the four sign bytes
+// [RE.low, RE.high, RE+1.low, RE+1.high], one shift + one v_and_or_b32 drops the four sign bits into the word of the
+// 16-register group (1.5 instructions per register instead of shift + and + or per register).  acc collects the
+// COMPLEMENT of the decisions at bit k15_decision_bit(true, rho, half) (k15_layout.h).
+template <int RE, int NA>
+__device__ __forceinline__ void put_signs(i16x2 we, i16x2 wo, unsigned (&acc)[NA]) {
+    static_assert((RE & 1) == 0, "pairs start at an even register");
+    constexpr int i8 = (RE & 15) >> 1;
+    const unsigned P = __builtin_amdgcn_perm(as_u32(wo), as_u32(we), 0x07050301u);
+    acc[RE >> 4] = ((P >> i8) & (0x80808080u >> i8)) | acc[RE >> 4];
 }
 
 // spiral615 flavour (spiral/spiral615.cpp:220-227): u8 saturating metrics held as (m<<8)|0xff in 16-bit fields so that
@@ -162,9 +170,9 @@ __device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R],
             TAp[c] = TA[c] | (TA[c ^ (ch & 7u)] << 16);
             TBp[c] = TB[c] | (TB[c ^ (ch >> 3)] << 16);
         }
-        sfor<NR / 2>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            constexpr int r0 = ((i >> rb) << (rb + 1)) | (i & ((1 << rb) - 1));
+        // one butterfly pair of registers (r0, r1 = r0 | 1<<rb); W0/W1 receive the decision differences (ka9q615)
+        auto pair = [&](auto R0, i16x2 &W0, i16x2 &W1) {
+            constexpr int r0 = decltype(R0)::value;
             constexpr int r1 = r0 | (1 << rb);
             constexpr unsigned cr = cls(rotl14(((unsigned)r0 << 1) << FSH, PHI));
             unsigned tp, tq;
@@ -175,14 +183,43 @@ __device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R],
                 M[r0] = acs_u8<(r0 & 7) + 1>(m0, m1, acc[r0 >> 3]);
                 M[r1] = acs_u8<(r1 & 7) + 1>(m2, m3, acc[r1 >> 3]);
             } else {
-                M[r0] = acs<(r0 & 15)>(m0, m1, acc[r0 >> 4]);
-                M[r1] = acs<(r1 & 15)>(m2, m3, acc[r1 >> 4]);
+                M[r0] = acs(m0, m1, W0);
+                M[r1] = acs(m2, m3, W1);
             }
-        });
+        };
+        if constexpr (SP) {
+            sfor<NR / 2>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                constexpr int r0 = ((i >> rb) << (rb + 1)) | (i & ((1 << rb) - 1));
+                i16x2 w0, w1;
+                pair(std::integral_constant<int, r0>{}, w0, w1);
+            });
+        } else if constexpr (rb == 0) {
+            // the butterfly pair (2i, 2i+1) is also the sign-gathering pair
+            sfor<NR / 2>([&](auto I) {
+                constexpr int r0 = 2 * decltype(I)::value;
+                i16x2 w0, w1;
+                pair(std::integral_constant<int, r0>{}, w0, w1);
+                put_signs<r0>(w0, w1, acc);
+            });
+        } else {
+            // two butterfly pairs (r0, r1), (r0+1, r1+1) feed the sign-gathering pairs (r0, r0+1) and (r1, r1+1)
+            sfor<NR / 4>([&](auto I) {
+                constexpr int i = 2 * decltype(I)::value;
+                constexpr int r0 = ((i >> rb) << (rb + 1)) | (i & ((1 << rb) - 1));
+                constexpr int r1 = r0 | (1 << rb);
+                static_assert((r0 & 1) == 0, "even/odd neighbours");
+                i16x2 wa0, wa1, wb0, wb1;
+                pair(std::integral_constant<int, r0>{}, wa0, wa1);
+                pair(std::integral_constant<int, r0 + 1>{}, wb0, wb1);
+                put_signs<r0>(wa0, wb0, acc);
+                put_signs<r1>(wa1, wb1, acc);
+            });
+        }
     } else {
         // half stage: old[j] is the low field, old[j+H] the high field of the same register
-        sfor<NR>([&](auto I) {
-            constexpr int r0 = decltype(I)::value;
+        auto half = [&](auto R0, i16x2 &W) {
+            constexpr int r0 = decltype(R0)::value;
             constexpr unsigned cr = cls(rotl14(((unsigned)r0 << 1) << FSH, PHI));
             unsigned tpp, tqq;
             fields(TA[cr & 7u] + TB[cr >> 3], tpp, tqq);  // low fields: t and t' of this butterfly
@@ -192,7 +229,14 @@ __device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R],
             const i16x2 V = madd<SP>(A, tc | (t << 16));  // (m2, m3)
             const i16x2 lower = {U.x, V.x}, upper = {U.y, V.y};
             if constexpr (SP) M[r0] = acs_u8<(r0 & 7) + 1>(lower, upper, acc[r0 >> 3]);
-            else M[r0] = acs<(r0 & 15)>(lower, upper, acc[r0 >> 4]);
+            else M[r0] = acs(lower, upper, W);
+        };
+        sfor<NR / 2>([&](auto I) {
+            constexpr int r0 = 2 * decltype(I)::value;
+            i16x2 w0, w1;
+            half(std::integral_constant<int, r0>{}, w0);
+            half(std::integral_constant<int, r0 + 1>{}, w1);
+            if constexpr (!SP) put_signs<r0>(w0, w1, acc);
         });
     }
 #pragma unroll
@@ -369,7 +413,7 @@ __global__ __launch_bounds__(64) void chainback_k15_kernel(ChainbackRowsArgs a) 
             const unsigned t = phi < 7 ? (p & 127u) : (p >> 7), q = phi < 7 ? (p >> 7) : (p & 127u);
             const unsigned rho = q >> 1, h = q & 1u;
             const unsigned word = rows[r * 512L + (rho >> 4) * 128 + t];
-            k = (word >> ((rho & 15u) + 16u * h)) & 1u;
+            k = (word >> k15_decision_bit(a.k15_sign_bytes != 0, rho, h)) & 1u;
         }
         e = (k << (K - 2)) | (e >> 1);                                   // viterbi615_sse2.cpp:87
         if ((i & 7u) == 0) out[i >> 3] = (unsigned char)(e >> sub);      // :88

@@ -11,12 +11,13 @@
 // instead of six -- the history is far larger than the bytes touched either way.
 #include <hip/hip_runtime.h>
 
+#include "k15_layout.h"
 #include "k24f_layout.h"
 #include "kernels.h"
 
 namespace vh {
 
-enum { LAY_NATURAL = 0, LAY_K15 = 1, LAY_K24F = 2 };
+enum { LAY_NATURAL = 0, LAY_K15 = 1, LAY_K24F = 2, LAY_K15_SIGN_BYTES = 3 };
 
 // decision bit of new state `st` at row r for each layout
 template <int LAY, int K>
@@ -29,12 +30,12 @@ __device__ __forceinline__ unsigned fetch_bit(const unsigned char *rows, long r,
     } else {
         const int rot = (int)((r + 1) % NB);
         const unsigned p = rot == 0 ? st : (((st >> rot) | (st << (NB - rot))) & (N - 1u));
-        if constexpr (LAY == LAY_K15) {
+        if constexpr (LAY == LAY_K15 || LAY == LAY_K15_SIGN_BYTES) {
             const int phi = rot == 0 ? NB - 1 : rot - 1;
             const unsigned t = phi < 7 ? (p & 127u) : (p >> 7), q = phi < 7 ? (p >> 7) : (p & 127u);
             const unsigned rho = q >> 1, h = q & 1u;
             const unsigned w = reinterpret_cast<const unsigned *>(rows)[r * 512L + (rho >> 4) * 128 + t];
-            return (w >> ((rho & 15u) + 16u * h)) & 1u;
+            return (w >> k15_decision_bit(LAY == LAY_K15_SIGN_BYTES, rho, h)) & 1u;
         } else {
             unsigned widx, wbit;
             k24f_locate(p, rot == 0 ? NB - 1 : rot - 1, widx, wbit);
@@ -97,6 +98,7 @@ hipError_t launch_chainback_spec(int layout, const ChainbackRowsArgs &a, hipStre
     const dim3 grid(a.nframes), block(64);
     if (a.K == 15 && layout == LAY_NATURAL) hipLaunchKernelGGL((chainback_spec_kernel<LAY_NATURAL, 15, false>), grid, block, 0, stream, a);
     else if (a.K == 15 && layout == LAY_K15) hipLaunchKernelGGL((chainback_spec_kernel<LAY_K15, 15, false>), grid, block, 0, stream, a);
+    else if (a.K == 15 && layout == LAY_K15_SIGN_BYTES) hipLaunchKernelGGL((chainback_spec_kernel<LAY_K15_SIGN_BYTES, 15, false>), grid, block, 0, stream, a);
     else if (a.K == 24 && layout == LAY_NATURAL) hipLaunchKernelGGL((chainback_spec_kernel<LAY_NATURAL, 24, true>), grid, block, 0, stream, a);
     else if (a.K == 24 && layout == LAY_K24F) hipLaunchKernelGGL((chainback_spec_kernel<LAY_K24F, 24, true>), grid, block, 0, stream, a);
     else return hipErrorInvalidValue;

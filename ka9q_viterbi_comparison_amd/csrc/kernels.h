@@ -78,6 +78,7 @@ struct ChainbackRowsArgs {
     unsigned endstate;
     int K;
     int k224;                  // chainback_viterbi224_sse2 semantics (no tail skip, emits state&1)
+    int k15_sign_bytes = 0;    // acs_k15 rows in the ka9q615 bit order (k15_layout.h)
 };
 hipError_t launch_chainback_rows(const ChainbackRowsArgs &a, hipStream_t stream);
 
@@ -95,7 +96,7 @@ hipError_t launch_k24f_pass(int g, const int16_t *oldm, int16_t *newm, unsigned 
 hipError_t launch_chainback_k24f(const ChainbackRowsArgs &a, hipStream_t stream);
 
 // ---------------------------------------------------------------- chainback_spec.hip (K = 15 / 24, one wave per frame)
-enum { CB_LAY_NATURAL = 0, CB_LAY_K15 = 1, CB_LAY_K24F = 2 };
+enum { CB_LAY_NATURAL = 0, CB_LAY_K15 = 1, CB_LAY_K24F = 2, CB_LAY_K15_SIGN_BYTES = 3 };
 hipError_t launch_chainback_spec(int layout, const ChainbackRowsArgs &a, hipStream_t stream);
 
 // ---------------------------------------------------------------- framegen.hip

@@ -17,6 +17,7 @@
 
 #include "../../include/viterbi_hip.h"
 #include "framegen.h"
+#include "k15_layout.h"
 #include "k24f_layout.h"
 #include "kernels.h"
 #include "viterbi_codes.h"
@@ -552,8 +553,9 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
         a.endstate = endstate;
         a.K = p->K;
         a.k224 = 0;
+        a.k15_sign_bytes = p->code == VHIP_KA9Q615;
         if (getenv("VHIP_CHAINBACK_SIMPLE")) HIP_TRY(vh::launch_chainback_k15(a, p->stream));
-        else HIP_TRY(vh::launch_chainback_spec(vh::CB_LAY_K15, a, p->stream));
+        else HIP_TRY(vh::launch_chainback_spec(a.k15_sign_bytes ? vh::CB_LAY_K15_SIGN_BYTES : vh::CB_LAY_K15, a, p->stream));
         return 0;
     }
     if (p->variant == VHIP_VARIANT_REGS) {
@@ -658,7 +660,8 @@ int vhip_read_decision_rows(vhip_decoder *p, int frame, int row0, int nrows, uns
                 const unsigned t = phi < 7 ? (pos & 127u) : (pos >> 7), q = phi < 7 ? (pos >> 7) : (pos & 127u);
                 const unsigned rho = q >> 1, h = q & 1u;
                 const unsigned word = raw[(size_t)i * 512 + (rho >> 4) * 128 + t];
-                if ((word >> ((rho & 15u) + 16u * h)) & 1u) out[(size_t)i * p->row_bytes + (n >> 3)] |= (unsigned char)(1u << (n & 7));
+                if ((word >> vh::k15_decision_bit(p->code == VHIP_KA9Q615, rho, h)) & 1u)
+                    out[(size_t)i * p->row_bytes + (n >> 3)] |= (unsigned char)(1u << (n & 7));
             }
         }
         return 0;
