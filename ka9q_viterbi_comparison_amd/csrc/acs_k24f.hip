@@ -18,7 +18,7 @@
 // 1.47x faster than two serial ones with 128 positions per thread -- tools/k24_overlap_probe.py).
 //
 // Decision row r (1 MiB) is stored as the kernels produce it: [thread u of the pass][accumulator words], 32 bits per
-// 16 registers (bit (rho & 15) + 16*half).  k24f_locate() in k24f_layout.h maps a position to (word, bit); the decision
+// 16 registers (bit k24f_decision_bit(rho, half)).  k24f_locate() in k24f_layout.h maps a position to (word, bit); the decision
 // of new state n at row r is at position rotr^((r+1) mod 23)(n).
 #include <hip/hip_runtime.h>
 
@@ -73,13 +73,19 @@ constexpr int group_vw(int g) { return k24f_vw(g); }          // 2 or 4 for the 
 constexpr int group_nr(int g) { return 16 * group_vw(g) / 2; }  // packed registers per thread
 
 // packed ACS, tie -> lower (cmpgt_epi16 then min_epi16, viterbi224_sse2.cpp:190-194); acc gets the decision bits
-template <int KB>
-__device__ __forceinline__ i16x2 acs(i16x2 lower, i16x2 upper, unsigned &acc) {
-    const i16x2 w = __builtin_elementwise_sub_sat(upper, lower);  // < 0  <=>  upper < lower  <=>  decision 1
-    const i16x2 full = w >> 15;
-    constexpr unsigned mask = (1u << KB) | (1u << (16 + KB));
-    acc = (as_u32(full) & mask) | (acc & ~mask);
+__device__ __forceinline__ i16x2 acs(i16x2 lower, i16x2 upper, i16x2 &w) {
+    w = __builtin_elementwise_sub_sat(upper, lower);  // < 0  <=>  upper < lower  <=>  decision 1
     return __builtin_elementwise_min(lower, upper);
+}
+// Decision bits of the register pair (RE, RE+1), RE even: one v_perm_b32 gathers the four sign bytes
+// [RE.low, RE.high, RE+1.low, RE+1.high]; a shift and a masked OR drop the four sign bits into the word of the
+// 16-register group at bit k24f_decision_bit(rho, half) (k24f_layout.h).
+template <int RE, int NA>
+__device__ __forceinline__ void put_signs(i16x2 we, i16x2 wo, unsigned (&acc)[NA]) {
+    static_assert((RE & 1) == 0, "pairs start at an even register");
+    constexpr int i8 = (RE & 15) >> 1;
+    const unsigned P = __builtin_amdgcn_perm(as_u32(wo), as_u32(we), 0x07050301u);
+    acc[RE >> 4] = ((P >> i8) & (0x80808080u >> i8)) | acc[RE >> 4];
 }
 
 // One trellis step at phase PHI.  pt = the thread-id part of the position (vector-index and low bits zero).
@@ -113,29 +119,57 @@ __device__ __forceinline__ void stage(i16x2 (&M)[group_nr(G)], unsigned s0, unsi
             TP[c] = T[c] | (T[c ^ ch] << 16);
             TQ[c] = COMP * 0x10001u - TP[c];
         }
-        sfor<NR / 2>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            constexpr int r0 = ((i >> rb) << (rb + 1)) | (i & ((1 << rb) - 1));
+        auto pair = [&](auto R0, i16x2 &W0, i16x2 &W1) {
+            constexpr int r0 = decltype(R0)::value;
             constexpr int r1 = r0 | (1 << rb);
             constexpr unsigned cr = cls(rotl23(spos(r0), PHI));
             const i16x2 A = M[r0], B = M[r1];
             const i16x2 tp = as_v(TP[cr]), tq = as_v(TQ[cr]);
             const i16x2 m0 = __builtin_elementwise_add_sat(A, tp), m1 = __builtin_elementwise_add_sat(B, tq);  // adds_epi16 :163-166
             const i16x2 m2 = __builtin_elementwise_add_sat(A, tq), m3 = __builtin_elementwise_add_sat(B, tp);
-            M[r0] = acs<(r0 & 15)>(m0, m1, acc[r0 >> 4]);
-            M[r1] = acs<(r1 & 15)>(m2, m3, acc[r1 >> 4]);
-        });
+            M[r0] = acs(m0, m1, W0);
+            M[r1] = acs(m2, m3, W1);
+        };
+        if constexpr (rb == 0) {
+            // the butterfly pair (2i, 2i+1) is also the sign-gathering pair
+            sfor<NR / 2>([&](auto I) {
+                constexpr int r0 = 2 * decltype(I)::value;
+                i16x2 w0, w1;
+                pair(std::integral_constant<int, r0>{}, w0, w1);
+                put_signs<r0>(w0, w1, acc);
+            });
+        } else {
+            // two butterfly pairs (r0, r1), (r0+1, r1+1) feed the sign-gathering pairs (r0, r0+1) and (r1, r1+1)
+            sfor<NR / 4>([&](auto I) {
+                constexpr int i = 2 * decltype(I)::value;
+                constexpr int r0 = ((i >> rb) << (rb + 1)) | (i & ((1 << rb) - 1));
+                constexpr int r1 = r0 | (1 << rb);
+                static_assert((r0 & 1) == 0, "even/odd neighbours");
+                i16x2 wa0, wa1, wb0, wb1;
+                pair(std::integral_constant<int, r0>{}, wa0, wa1);
+                pair(std::integral_constant<int, r0 + 1>{}, wb0, wb1);
+                put_signs<r0>(wa0, wb0, acc);
+                put_signs<r1>(wa1, wb1, acc);
+            });
+        }
     } else {
         // half stage (position bit 0): old[j] low field, old[j+H] high field
-        sfor<NR>([&](auto I) {
-            constexpr int r0 = decltype(I)::value;
+        auto half = [&](auto R0, i16x2 &W) {
+            constexpr int r0 = decltype(R0)::value;
             constexpr unsigned cr = cls(rotl23(spos(r0), PHI));
             const unsigned t = T[cr], tc = COMP - t;
             const i16x2 A = M[r0];
             const i16x2 U = __builtin_elementwise_add_sat(A, as_v(t | (tc << 16)));
             const i16x2 V = __builtin_elementwise_add_sat(A, as_v(tc | (t << 16)));
             const i16x2 lower = {U.x, V.x}, upper = {U.y, V.y};
-            M[r0] = acs<(r0 & 15)>(lower, upper, acc[r0 >> 4]);
+            M[r0] = acs(lower, upper, W);
+        };
+        sfor<NR / 2>([&](auto I) {
+            constexpr int r0 = 2 * decltype(I)::value;
+            i16x2 w0, w1;
+            half(std::integral_constant<int, r0>{}, w0);
+            half(std::integral_constant<int, r0 + 1>{}, w1);
+            put_signs<r0>(w0, w1, acc);
         });
     }
 }
