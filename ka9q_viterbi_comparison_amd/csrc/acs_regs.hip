@@ -735,10 +735,157 @@ __global__ __launch_bounds__(64) void chainback_regs_lds_kernel(ChainbackRegsArg
     }
 }
 
+// K=7, one lane per frame (LB = 0): the whole 64-bit decision row of a frame is the lane's own two words, so the LDS
+// reads do not depend on the state at all and are issued ahead of the walk; only ALU work is left on the serial chain.
+// The walk runs in POSITION space: position p = rotr^rot(state) holds the state (rot = (row+1) mod 6), and one
+// traceback step  state' = (state >> 1) | (k << 5)  is  p' = p with bit (6 - rot) mod 6 replaced by k  -- the same
+// rotating map the ACS kernel uses, so nothing is rotated per row.  q = the bit index of p inside the row (a fixed
+// permutation of p's bits) is what is kept: k = (row >> q) & 1, then one bit of q is replaced: three dependent
+// instructions per decoded bit instead of a dependent LDS round trip.  A block is 32 rows = one output dword; the phase
+// of the six-row period at its first row is uniform, so each of the six phases gets its own unrolled walk with
+// compile-time bit indices.
+// Decoded bytes: a lane's bytes are 256 B apart from its neighbours', so a byte store per 8 rows is 64 separate lines per
+// instruction, and any store narrower than a 32-byte sector is a read-modify-write once the streaming history has pushed
+// the line out of L2 -- measured for 65536 frames: byte stores 0.27 ms, 12-byte stores 0.23 ms, 32-byte 0.21 ms, 64-byte
+// 0.195 ms, 128-byte 0.188 ms, no stores 0.18 ms for the same walk (tools/hbm_read_probe.hip shows the same on a bare
+// stream).  The dwords of a 1024-row window are parked in LDS and leave as one whole 128-byte line per lane.  Same bytes out as chainback_viterbi27_sse2 (viterbi27_sse2.cpp:78-105): the top byte of
+// the 32-bit history is the reference's 8-bit register e.
+template <int D, int WD>
+__global__ __launch_bounds__(64) void chainback_k7_lds_kernel(ChainbackRegsArgs a) {
+    constexpr int K = 7, NB = 6, RS = 512, GB = D * RS, add = 2;
+    static_assert(WD == 8 || WD == 16 || WD == 32, "output window in dwords");
+    constexpr unsigned N = 64;
+    static_assert(D == 32 && GB % 1024 == 0, "one dword of output per block, whole DMA chunks");
+    constexpr int NBUF = 2;  // a three-deep ring (two blocks in flight behind s_waitcnt vmcnt(n)) measured the same
+    __shared__ __attribute__((aligned(16))) unsigned char ring[NBUF * GB];
+    __shared__ unsigned stash[WD * 64];  // [dword of the output window][lane]
+
+    const unsigned lane = threadIdx.x;
+    const long f0 = (long)blockIdx.x * 64 + lane;
+    const bool active = f0 < a.nframes;
+    unsigned char *out = a.data + (active ? f0 : (long)a.nframes - 1) * (long)a.data_stride;
+    const unsigned char *wave_dec = a.dec + ((long)blockIdx.x * a.cap_rows) * RS;
+    unsigned e = (a.endstate % N) << add;
+    int rot = (int)(a.nbits % NB);
+
+    auto advance = [&](unsigned i, unsigned k) {
+        e = (e >> 1) | (k << (K - 2 + add));
+        if ((i & 7u) == 0 && active) out[i >> 3] = (unsigned char)e;
+        rot = rot == 0 ? NB - 1 : rot - 1;
+    };
+    // bit index of position p inside the 64-bit row: word p>>5, bit ((p>>1) & 15) + 16 * (p & 1)
+    auto row_bit = [](unsigned p) { return (p & 32u) | ((p & 1u) << 4) | ((p >> 1) & 15u); };
+    auto position = [&]() {
+        const unsigned st = e >> add;
+        return rot == 0 ? st : (((st >> rot) | (st << (NB - rot))) & (N - 1));
+    };
+    auto issue = [&](int b, long r_lo) {
+        const unsigned char *src = wave_dec + r_lo * RS + lane * 16;
+#pragma unroll
+        for (int c = 0; c < GB / 1024; c++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + c * 1024),
+                                             (__attribute__((address_space(3))) void *)(ring + b * GB + c * 1024), 16, 0, 0);
+    };
+    // cnt <= 64 rows below i, through LDS with a dependent read per row and the reference's byte stores
+    auto slow_rows = [&](unsigned &i, unsigned cnt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned lo = i - cnt;
+        const unsigned char *src = wave_dec + ((long)lo + NB) * RS + lane * 16;
+        for (unsigned c = 0; c < cnt / 2; c++)  // two rows per 1 KiB instruction
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + c * 1024),
+                                             (__attribute__((address_space(3))) void *)(ring + c * 1024), 16, 0, 0);
+        if ((cnt & 1u) && lane < 32)  // an odd last row: half an instruction, nothing is read beyond row NB+i-1
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (cnt / 2) * 1024),
+                                             (__attribute__((address_space(3))) void *)(ring + (cnt / 2) * 1024), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned *blk = reinterpret_cast<const unsigned *>(ring) + lane;
+        while (i > lo) {
+            --i;
+            const unsigned qq = row_bit(position());
+            const unsigned word = blk[(i - lo) * (RS / 4) + (qq >> 5) * 64];
+            advance(i, (word >> (qq & 31u)) & 1u);
+        }
+    };
+
+    unsigned i = a.nbits;
+    while (i > 0 && (long)(i - 1) + NB >= a.rows_written) {  // rows never written read as zero
+        --i;
+        advance(i, 0);
+    }
+    const bool out_aligned = ((reinterpret_cast<uintptr_t>(a.data) | a.data_stride) & 3) == 0;
+    if (out_aligned && i >= (unsigned)D + (i & 31u)) {
+        if (i & 31u) slow_rows(i, i & 31u);  // blocks start on a dword of the output
+        const unsigned nblk = i / D;
+        unsigned q = row_bit(position());
+        unsigned h = e << 24;  // the last 32 decisions, newest at bit 31
+        // one block: rows i-1 ... i-D out of buffer blk; ROT0 = rot at the block's first row
+        auto walk = [&](auto R0, const unsigned *blk) {
+            constexpr int ROT0 = decltype(R0)::value;
+            constexpr int PI[6] = {4, 0, 1, 2, 3, 5};  // position bit -> row-index bit
+            unsigned long long W[D];
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                const unsigned *wp = blk + (D - 1 - d) * (RS / 4);
+                W[d] = (unsigned long long)wp[0] | ((unsigned long long)wp[64] << 32);
+            }
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                const int rotd = ((ROT0 - d) % NB + NB) % NB;    // rot at row i-1-d
+                const int jb = PI[(NB - rotd) % NB];             // the position bit replaced there
+                const unsigned t = (unsigned)(W[d] >> q);        // bit 0 = the decision
+                q = (q & ~(1u << jb)) | ((t << jb) & (1u << jb));
+                h = (h >> 1) | (t << 31);
+            }
+        };
+        // block n covers rows i0-1-n*D ... i0-(n+1)*D and lives in buffer n % NBUF
+        const unsigned i0 = i;
+        issue(0, (long)(i0 - D) + NB);
+        unsigned parked = 0;  // dwords of the current 256-row window waiting in the stash
+        for (unsigned b = 0; b < nblk; b++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // block b has landed (single wave: no barrier needed)
+            if (b + 1 < nblk) issue((int)((b + 1) & 1u), (long)(i0 - (b + 2) * D) + NB);
+            const unsigned *blk = reinterpret_cast<const unsigned *>(ring + (b & 1u) * GB) + lane;
+            switch (rot) {  // uniform
+            case 0: walk(std::integral_constant<int, 0>{}, blk); break;
+            case 1: walk(std::integral_constant<int, 1>{}, blk); break;
+            case 2: walk(std::integral_constant<int, 2>{}, blk); break;
+            case 3: walk(std::integral_constant<int, 3>{}, blk); break;
+            case 4: walk(std::integral_constant<int, 4>{}, blk); break;
+            default: walk(std::integral_constant<int, 5>{}, blk); break;
+            }
+            rot = (rot + NB * 6 - D) % NB;
+            i -= D;
+            // h = rows i ... i+31, row i on top = the four bytes at out[i/8 ...], first byte in the top bits
+            stash[((i >> 5) & (WD - 1)) * 64 + lane] = __builtin_bswap32(h);
+            parked++;
+            if ((i & (32u * WD - 1)) == 0 || b + 1 == nblk) {
+                if (active) {
+                    const unsigned *sp = stash + ((i >> 5) & (WD - 1)) * 64 + lane;
+                    unsigned *o = reinterpret_cast<unsigned *>(out + (i >> 3));
+                    if (parked == (unsigned)WD) {  // the whole window: WD * 4 contiguous, aligned bytes per lane
+#pragma unroll
+                        for (int k = 0; k < WD / 4; k++)
+                            reinterpret_cast<uint4 *>(o)[k] = make_uint4(sp[(4 * k) * 64], sp[(4 * k + 1) * 64], sp[(4 * k + 2) * 64], sp[(4 * k + 3) * 64]);
+                    } else {
+                        for (unsigned k = 0; k < parked; k++) o[k] = sp[k * 64];
+                    }
+                }
+                parked = 0;
+            }
+        }
+        e = h >> 24;
+    }
+    while (i > 0) slow_rows(i, i < 64u ? i : 64u);  // what is left
+}
+
 hipError_t launch_chainback_regs(const ChainbackRegsArgs &a, hipStream_t stream) {
     const int blocks = (a.nframes + 63) / 64;
     const bool pipe = getenv("VHIP_CHAINBACK_SIMPLE") == nullptr;
     if (pipe && !getenv("VHIP_CHAINBACK_PIPE")) {  // default: LDS-staged (K=9: 0.93 -> 0.48 ms on 32768 frames)
+        if (a.K == 7 && a.lay.lb == 0 && !getenv("VHIP_CHAINBACK_GENERIC_LDS")) {
+            hipLaunchKernelGGL((chainback_k7_lds_kernel<32, 32>), dim3(blocks), dim3(64), 0, stream, a);
+            return hipGetLastError();
+        }
 #define VH_CBL(KK, LBB, DD)                                                                                      \
     if (a.K == KK && a.lay.lb == LBB) {                                                                          \
         hipLaunchKernelGGL((chainback_regs_lds_kernel<KK, LBB, DD>), dim3(blocks), dim3(64), 0, stream, a);      \
