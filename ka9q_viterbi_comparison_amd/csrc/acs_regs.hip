@@ -663,9 +663,10 @@ __global__ __launch_bounds__(64) void chainback_regs_lds_kernel(ChainbackRegsArg
     constexpr int RS = DW * 64 * WB;       // bytes of one row of one group
     constexpr int GB = D * RS;             // bytes of one group's block
     constexpr int BUF = GPW * GB;          // bytes per buffer
-    static_assert(GB % 1024 == 0 && 2 * BUF <= 65536, "block geometry");
+    static_assert(GB % 1024 == 0 && 2 * BUF + 8192 <= 65536, "block geometry");
     constexpr int add = (NB < 8) ? 8 - NB : 0, sub = (NB > 8) ? NB - 8 : 0;
     __shared__ __attribute__((aligned(16))) unsigned char ring[2 * BUF];
+    __shared__ unsigned stash[32 * 64];  // [dword of the 128-byte output window][lane]
 
     const unsigned lane = threadIdx.x;
     const long f0 = (long)blockIdx.x * 64 + lane;
@@ -678,9 +679,36 @@ __global__ __launch_bounds__(64) void chainback_regs_lds_kernel(ChainbackRegsArg
     unsigned e = (a.endstate % N) << add;
     int rot = (int)(a.nbits % NB);
 
+    // Decoded bytes: neighbouring lanes' bytes are a frame apart, so a byte store per 8 rows is 64 separate lines per
+    // instruction and every one a read-modify-write (see chainback_k7_lds_kernel below for the measurements).  h holds
+    // the last 32 decisions (its top byte is the reference's output register); every 32 rows it is one dword of the
+    // output, parked in LDS, and a 1024-row window leaves as one whole 128-byte line per lane.  Rows at or above
+    // dword_top belong to a dword whose upper bytes lie beyond nbits: they keep the reference's byte stores.
+    static_assert(sub == 0 && K - 2 + add == 7, "e is the 8-bit output register itself");
+    const bool out_aligned = ((reinterpret_cast<uintptr_t>(a.data) | a.data_stride) & 3) == 0;
+    const unsigned last_byte_row = a.nbits ? ((a.nbits - 1u) & ~7u) : 0u;
+    const unsigned dword_top = (!out_aligned || last_byte_row < 24u) ? 0u : ((last_byte_row - 24u) / 32u + 1u) * 32u;
+    unsigned h = e << 24;
     auto advance = [&](unsigned i, unsigned k) {
         e = (e >> 1) | (k << (K - 2 + add));
-        if ((i & 7u) == 0 && active) out[i >> 3] = (unsigned char)(e >> sub);
+        h = (h >> 1) | (k << 31);
+        if (i >= dword_top) {
+            if ((i & 7u) == 0 && active) out[i >> 3] = (unsigned char)(e >> sub);
+        } else if ((i & 31u) == 0) {
+            stash[((i >> 5) & 31u) * 64 + lane] = __builtin_bswap32(h);
+            if ((i & 1023u) == 0 && active) {  // window [i, i+1024) below dword_top is complete
+                const unsigned top = i + 1024u < dword_top ? i + 1024u : dword_top, cnt = (top - i) / 32u;
+                const unsigned *sp = stash + lane;
+                unsigned *o = reinterpret_cast<unsigned *>(out + (i >> 3));
+                if (cnt == 32u) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++)
+                        reinterpret_cast<uint4 *>(o)[q] = make_uint4(sp[(4 * q) * 64], sp[(4 * q + 1) * 64], sp[(4 * q + 2) * 64], sp[(4 * q + 3) * 64]);
+                } else {
+                    for (unsigned q = 0; q < cnt; q++) o[q] = sp[q * 64];
+                }
+            }
+        }
         rot = rot == 0 ? NB - 1 : rot - 1;
     };
     auto locate = [&](unsigned &woff, unsigned &bit) {  // byte offset inside a group row, bit inside the word
@@ -714,13 +742,32 @@ __global__ __launch_bounds__(64) void chainback_regs_lds_kernel(ChainbackRegsArg
             __syncthreads();  // block b has landed (hipcc drains vmcnt here); every lane is done with the other buffer
             if (b + 1 < nblk) issue((int)((b + 1) & 1u), (long)(i - 2 * D) + NB);
             const unsigned char *blk = ring + (b & 1u) * BUF + gl * GB;
+            // Rows [i-D, i).  Almost every block lies wholly below dword_top and inside one 1024-row output window: its
+            // rows then need no decision about the output at all -- h is parked on every row (the row that completes
+            // a dword writes last, rows descend), which keeps scalar branches off the per-row path.
+            const bool lean = i <= dword_top && ((i - 1u) >> 10) == ((i - D) >> 10) && ((i - D) & 1023u) != 0;
+            if (lean) {
 #pragma unroll 4
-            for (int d = 0; d < D; d++) {
-                unsigned woff, bit;
-                locate(woff, bit);
-                const unsigned char *wp = blk + (D - 1 - d) * RS + woff;
-                const unsigned word = WB == 4 ? *reinterpret_cast<const unsigned *>(wp) : *reinterpret_cast<const unsigned short *>(wp);
-                advance(i - 1 - d, (word >> bit) & 1u);
+                for (int d = 0; d < D; d++) {
+                    unsigned woff, bit;
+                    locate(woff, bit);
+                    const unsigned char *wp = blk + (D - 1 - d) * RS + woff;
+                    const unsigned word = WB == 4 ? *reinterpret_cast<const unsigned *>(wp) : *reinterpret_cast<const unsigned short *>(wp);
+                    const unsigned k = (word >> bit) & 1u;
+                    e = (e >> 1) | (k << (K - 2 + add));
+                    h = (h >> 1) | (k << 31);
+                    stash[(((i - 1 - d) >> 5) & 31u) * 64 + lane] = __builtin_bswap32(h);
+                    rot = rot == 0 ? NB - 1 : rot - 1;
+                }
+            } else {
+#pragma unroll 2
+                for (int d = 0; d < D; d++) {
+                    unsigned woff, bit;
+                    locate(woff, bit);
+                    const unsigned char *wp = blk + (D - 1 - d) * RS + woff;
+                    const unsigned word = WB == 4 ? *reinterpret_cast<const unsigned *>(wp) : *reinterpret_cast<const unsigned short *>(wp);
+                    advance(i - 1 - d, (word >> bit) & 1u);
+                }
             }
             i -= D;
         }
@@ -891,7 +938,7 @@ hipError_t launch_chainback_regs(const ChainbackRegsArgs &a, hipStream_t stream)
         hipLaunchKernelGGL((chainback_regs_lds_kernel<KK, LBB, DD>), dim3(blocks), dim3(64), 0, stream, a);      \
         return hipGetLastError();                                                                                \
     }
-        VH_CBL(7, 0, 32) VH_CBL(7, 1, 32) VH_CBL(7, 2, 32) VH_CBL(9, 0, 16) VH_CBL(9, 1, 16) VH_CBL(9, 2, 16)
+        VH_CBL(7, 0, 32) VH_CBL(7, 1, 32) VH_CBL(7, 2, 32) VH_CBL(9, 0, 12) VH_CBL(9, 1, 12) VH_CBL(9, 2, 12)
 #undef VH_CBL
     }
 #define VH_CB(KK, LBB, DD)                                                                                       \
