@@ -225,9 +225,10 @@ __device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R],
             fields(TA[cr & 7u] + TB[cr >> 3], tpp, tqq);  // low fields: t and t' of this butterfly
             const unsigned t = tpp & 0xffffu, tc = tqq & 0xffffu;
             const i16x2 A = M[r0];
-            const i16x2 U = madd<SP>(A, t | (tc << 16));  // (m0, m1)
-            const i16x2 V = madd<SP>(A, tc | (t << 16));  // (m2, m3)
-            const i16x2 lower = {U.x, V.x}, upper = {U.y, V.y};
+            // broadcasting one field to both lanes of a packed add is an op_sel modifier, not an instruction
+            const i16x2 Alo = {A.x, A.x}, Ahi = {A.y, A.y};
+            const i16x2 lower = madd<SP>(Alo, t | (tc << 16));  // (m0, m2) = old[j] + (t, t')
+            const i16x2 upper = madd<SP>(Ahi, tc | (t << 16));  // (m1, m3) = old[j+H] + (t', t)
             if constexpr (SP) M[r0] = acs_u8<(r0 & 7) + 1>(lower, upper, acc[r0 >> 3]);
             else M[r0] = acs(lower, upper, W);
         };

@@ -159,9 +159,10 @@ __device__ __forceinline__ void stage(i16x2 (&M)[group_nr(G)], unsigned s0, unsi
             constexpr unsigned cr = cls(rotl23(spos(r0), PHI));
             const unsigned t = T[cr], tc = COMP - t;
             const i16x2 A = M[r0];
-            const i16x2 U = __builtin_elementwise_add_sat(A, as_v(t | (tc << 16)));
-            const i16x2 V = __builtin_elementwise_add_sat(A, as_v(tc | (t << 16)));
-            const i16x2 lower = {U.x, V.x}, upper = {U.y, V.y};
+            // broadcasting one field to both lanes of a packed add is an op_sel modifier, not an instruction
+            const i16x2 Alo = {A.x, A.x}, Ahi = {A.y, A.y};
+            const i16x2 lower = __builtin_elementwise_add_sat(Alo, as_v(t | (tc << 16)));  // (m0, m2) = old[j] + (t, t')
+            const i16x2 upper = __builtin_elementwise_add_sat(Ahi, as_v(tc | (t << 16)));  // (m1, m3) = old[j+H] + (t', t)
             M[r0] = acs(lower, upper, W);
         };
         sfor<NR / 2>([&](auto I) {

@@ -244,9 +244,10 @@ struct RegsStep {
                 constexpr unsigned cr = cls_c<P, R>(rotl_c<NB>((unsigned)r0 << (LB + 1), PHI));
                 const unsigned t = T[cr], tc = ((unsigned)C::bm_comp << 8) - t;
                 const u16x2 A = M[r0];
-                const u16x2 U = madd<SAT>(A, as_v(t | (tc << 16)));   // (m0, m1)
-                const u16x2 V = madd<SAT>(A, as_v(tc | (t << 16)));   // (m2, m3)
-                const u16x2 lower = {U.x, V.x}, upper = {U.y, V.y};
+                // broadcasting one field to both lanes of a packed add is an op_sel modifier, not an instruction
+                const u16x2 Alo = {A.x, A.x}, Ahi = {A.y, A.y};
+                const u16x2 lower = madd<SAT>(Alo, as_v(t | (tc << 16)));   // (m0, m2) = old[j] + (t, t')
+                const u16x2 upper = madd<SAT>(Ahi, as_v(tc | (t << 16)));   // (m1, m3) = old[j+H] + (t', t)
                 M[r0] = acs_pk<SAT, (r0 & 7) + 1>(lower, upper, acc[r0 >> 3]);
             });
         } else {
