@@ -167,6 +167,37 @@ __device__ __forceinline__ void branch_fields(const unsigned (&s)[C::R], unsigne
     }
 }
 
+// Packed branch-metric fields for a register / lane stage: TP[c] = field(t(c)) | field(t(c ^ CH)) << 16.  For the r=1/4
+// spiral code the 16 sums are formed on both fields at once (sums <= 252 per field, no carry between them), which
+// halves the scalar-style arithmetic per class: (sum >> 2) << 8 per field is (sum2 << 6) & 0xff00ff00.
+template <class C, int NC, unsigned CH>
+__device__ __forceinline__ void branch_fields_paired(const unsigned (&s)[C::R], const unsigned (&T)[NC], unsigned (&TP)[NC]) {
+    if constexpr (C::metric == U8SAT && C::R == 4) {
+        unsigned g[4], h[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            g[r] = s[r] >> 2;
+            h[r] = g[r] ^ 63u;
+        }
+        unsigned p01[4], p23[4], x01[4], x23[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            p01[c] = ((c & 1) ? h[0] : g[0]) + ((c & 2) ? h[1] : g[1]);
+            p23[c] = ((c & 1) ? h[2] : g[2]) + ((c & 2) ? h[3] : g[3]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            x01[c] = p01[c] | (p01[c ^ (CH & 3u)] << 16);
+            x23[c] = p23[c] | (p23[c ^ (CH >> 2)] << 16);
+        }
+#pragma unroll
+        for (int c = 0; c < 16; c++) TP[c] = ((x01[c & 3] + x23[c >> 2]) << 6) & 0xff00ff00u;
+    } else {
+#pragma unroll
+        for (int c = 0; c < NC; c++) TP[c] = T[c] | (T[c ^ CH] << 16);
+    }
+}
+
 template <class C, class P, int LB>
 struct RegsStep {
     using G = RegsCfg<C, P, LB>;
@@ -204,9 +235,9 @@ struct RegsStep {
             constexpr int rb = b - (LB + 1);
             constexpr unsigned ch = cls_c<P, R>(rotl_c<NB>(1u << LB, PHI));
             unsigned TP[NC], TQ[NC], TE[NC];
+            branch_fields_paired<C, NC, ch>(s, T, TP);
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                TP[c] = T[c] | (T[c ^ ch] << 16);
                 TQ[c] = COMP2 - TP[c];
                 TE[c] = as_u32(as_v(TP[c]) - as_v(TQ[c]));  // t - t' per field (mod 2^16)
             }
@@ -254,11 +285,9 @@ struct RegsStep {
             // ---- lane stage: partner register lives in lane ^ (1<<b) of the same quad
             constexpr unsigned ch = cls_c<P, R>(rotl_c<NB>(1u << LB, PHI));
             unsigned TP[NC], TQ[NC];
+            branch_fields_paired<C, NC, ch>(s, T, TP);
 #pragma unroll
-            for (int c = 0; c < NC; c++) {
-                TP[c] = T[c] | (T[c ^ ch] << 16);
-                TQ[c] = COMP2 - TP[c];
-            }
+            for (int c = 0; c < NC; c++) TQ[c] = COMP2 - TP[c];
             const bool isY = (lam >> b) & 1u;  // this lane holds old[j+H] and will hold new[2j+1]
             static_for<NR>([&](auto I) {
                 constexpr int r0 = decltype(I)::value;
@@ -290,9 +319,27 @@ struct RegsStep {
             if constexpr (LB == 1) v0 = (unsigned)__builtin_amdgcn_mov_dpp((int)v0, 0xA0, 0xf, 0xf, true);  // [0,0,2,2]
             if constexpr (LB == 2) v0 = (unsigned)__builtin_amdgcn_mov_dpp((int)v0, 0x00, 0xf, 0xf, true);  // [0,0,0,0]
             const bool fire = v0 > (((unsigned)C::renorm_thr << 8) | 0xffu);  // spiral47.cpp:313
-            u16x2 mn = M[0];
+            // A single serial min chain makes every v_pk_min_u16 wait for its predecessor (hipcc pads it with s_nop).  A
+            // pairwise tree is what hipcc schedules best around the survivors' arithmetic for every geometry except
+            // K=7 r=1/2, where four interleaved chains (fewer live values) win -- measured, update ms tree / chains:
+            // spiral47 1.22 / 1.27, spiral49 2.46 / 2.67, spiral29 2.20 / 2.44, spiral27 1.25 / 1.18.
+            u16x2 mn;
+            if constexpr (!(R == 2 && NB == 6)) {
+                u16x2 tr[NR / 2];
 #pragma unroll
-            for (int i = 1; i < NR; i++) mn = __builtin_elementwise_min(mn, M[i]);
+                for (int i = 0; i < NR / 2; i++) tr[i] = __builtin_elementwise_min(M[2 * i], M[2 * i + 1]);
+#pragma unroll
+                for (int w = NR / 4; w >= 1; w /= 2) {
+#pragma unroll
+                    for (int i = 0; i < w; i++) tr[i] = __builtin_elementwise_min(tr[2 * i], tr[2 * i + 1]);
+                }
+                mn = tr[0];
+            } else {
+                u16x2 ch4[4] = {M[0], M[1], M[2], M[3]};
+#pragma unroll
+                for (int i = 4; i < NR; i++) ch4[i & 3] = __builtin_elementwise_min(ch4[i & 3], M[i]);
+                mn = __builtin_elementwise_min(__builtin_elementwise_min(ch4[0], ch4[1]), __builtin_elementwise_min(ch4[2], ch4[3]));
+            }
             const u16x2 sw = {mn.y, mn.x};
             mn = __builtin_elementwise_min(mn, sw);
             if constexpr (LB >= 1) mn = __builtin_elementwise_min(mn, dpp_xor<0>(mn));
