@@ -7,7 +7,10 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int BS, int ROWS>
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+// WORK > 0: WORK rounds of 4 packed ops on every loaded register between the loads and the stores (32 registers x 4 x
+// WORK wave instructions per thread; WORK = 4 is about the arithmetic of a 4-step ACS pass), VW2: 32 positions per thread
+template <int BS, int ROWS, int WORK = 0>
 __global__ __launch_bounds__(256) void strided_pass(const short *__restrict__ in, short *__restrict__ out, unsigned *__restrict__ rows) {
     const unsigned u = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned ulo = u & ((1u << (BS - 2)) - 1u), uhi = u >> (BS - 2);
@@ -16,6 +19,22 @@ __global__ __launch_bounds__(256) void strided_pass(const short *__restrict__ in
 #pragma unroll
     for (int v = 0; v < 16; v++) q[v] = *reinterpret_cast<const uint2 *>(in + (pt | ((unsigned)v << BS)));
     unsigned acc0 = 0, acc1 = 0;
+#pragma unroll
+    for (int w = 0; w < WORK; w++) {
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            i16x2 a = __builtin_bit_cast(i16x2, q[v].x), b = __builtin_bit_cast(i16x2, q[v].y);
+            const i16x2 t = {(short)(w + 3), (short)(w + 5)};
+            const i16x2 m0 = __builtin_elementwise_add_sat(a, t), m1 = __builtin_elementwise_add_sat(b, t);
+            a = __builtin_elementwise_min(m0, m1);
+            b = __builtin_elementwise_sub_sat(m0, m1);
+            const i16x2 m2 = __builtin_elementwise_add_sat(a, b), m3 = __builtin_elementwise_sub_sat(b, t);
+            a = __builtin_elementwise_min(m2, m3);
+            b = __builtin_elementwise_add_sat(m2, t);
+            q[v].x = __builtin_bit_cast(unsigned, a);
+            q[v].y = __builtin_bit_cast(unsigned, b);
+        }
+    }
 #pragma unroll
     for (int v = 0; v < 16; v++) { acc0 ^= q[v].x; acc1 ^= q[v].y; q[v].x += 1; }
 #pragma unroll
@@ -53,6 +72,9 @@ int main() {
     timeit("strided BS=19, 64 pos/thread, 4 rows", [&](int i) { hipLaunchKernelGGL((strided_pass<19, 4>), dim3(512), dim3(256), 0, 0, (i & 1) ? b : a, (i & 1) ? a : b, rows); });
     timeit("strided BS=11, 64 pos/thread, 4 rows", [&](int i) { hipLaunchKernelGGL((strided_pass<11, 4>), dim3(512), dim3(256), 0, 0, (i & 1) ? b : a, (i & 1) ? a : b, rows); });
     timeit("strided BS=7,  64 pos/thread, 4 rows", [&](int i) { hipLaunchKernelGGL((strided_pass<7, 4>), dim3(512), dim3(256), 0, 0, (i & 1) ? b : a, (i & 1) ? a : b, rows); });
+    timeit("strided BS=19, 4 rows + 8 ops/reg x 4 rounds", [&](int i) { hipLaunchKernelGGL((strided_pass<19, 4, 4>), dim3(512), dim3(256), 0, 0, (i & 1) ? b : a, (i & 1) ? a : b, rows); });
+    timeit("strided BS=19, 4 rows + 8 ops/reg x 8 rounds", [&](int i) { hipLaunchKernelGGL((strided_pass<19, 4, 8>), dim3(512), dim3(256), 0, 0, (i & 1) ? b : a, (i & 1) ? a : b, rows); });
+    timeit("strided BS=19, 4 rows + 8 ops/reg x 16 rounds", [&](int i) { hipLaunchKernelGGL((strided_pass<19, 4, 16>), dim3(512), dim3(256), 0, 0, (i & 1) ? b : a, (i & 1) ? a : b, rows); });
     timeit("strided BS=19, no rows", [&](int i) { hipLaunchKernelGGL((strided_pass<19, 0>), dim3(512), dim3(256), 0, 0, (i & 1) ? b : a, (i & 1) ? a : b, rows); });
     for (int blocks : {256, 512, 1024, 2048, 4096}) {
         char nm[64]; snprintf(nm, sizeof nm, "linear uint4, %d blocks, 4 rows", blocks);
