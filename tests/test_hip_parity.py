@@ -352,3 +352,33 @@ def test_arbitrary_polynomials(code):
         dec.close()
         with pytest.raises(VhipError):
             HipViterbi(spec.name, steps, nframes=1, poly=poly, variant=VARIANT_HBM_FUSED if spec.K == 24 else VARIANT_REGS)
+
+
+@pytest.mark.parametrize("code,variant", [(C.KA9Q27, regs(0)), (C.SPIRAL47, regs(0)), (C.KA9Q27, regs(2)), (C.KA9Q29, regs(1)), (C.SPIRAL49, regs(0))])
+def test_chainback_output_windows(code, variant):
+    """Long frames through the register-layout chainback kernels: whole 1024-row output windows (one 128-byte line per
+    lane), the partial window at the bottom, the byte-stored rows above the highest complete dword, bit counts and byte
+    strides that are not multiples of 32 / 4, non-zero end states, more than one wave of frames."""
+    spec = spec_of(code)
+    B = 270  # 2160 payload bits: two full output windows plus a partial one
+    steps = B * 8 + spec.K - 1  # even for K = 7 and K = 9: the spiral decoders drop nothing
+    nframes = 67
+    _, syms = frames(code, 4242, nframes, B, spec.ebn0_db)
+    dec = HipViterbi(spec.name, steps, nframes=nframes, variant=variant)
+    dec.reset()
+    dec.update(syms)
+    N = 1 << (spec.K - 1)
+    refs = {}
+    for nbits, end in [(B * 8, 0), (2048, 0), (2040, 5), (1031, N - 1), (1024 + 32, 0), (96, 1), (33, 0)]:
+        data, _ = dec.chainback(nbits, endstate=end)
+        for f in (0, 1, 63, 64, 66):
+            if f not in refs:
+                o = OracleDecoder(code, spec.poly, steps)
+                o.init(0)
+                o.update(syms[f], steps)
+                refs[f] = o
+            r, _ = refs[f].chainback(nbits, end)
+            assert np.array_equal(data[f], r), f"nbits {nbits} endstate {end} frame {f}"
+    for o in refs.values():
+        o.close()
+    dec.close()
