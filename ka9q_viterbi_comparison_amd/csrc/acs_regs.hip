@@ -286,17 +286,26 @@ struct RegsStep {
             constexpr unsigned ch = cls_c<P, R>(rotl_c<NB>(1u << LB, PHI));
             unsigned TP[NC], TQ[NC];
             branch_fields_paired<C, NC, ch>(s, T, TP);
+            // The X lane of a pair holds old[j] and will hold new[2j] = ACS(old[j]+t, old[j+H]+t'); the Y lane holds
+            // old[j+H] and will hold new[2j+1] = ACS(old[j]+t', old[j+H]+t).  Both lanes fetch old[j] and old[j+H] with two
+            // broadcasting DPP moves, and the lane-dependent choice between t and t' is made once per class and step
+            // instead of twice per register.
+            const bool isY = (lam >> b) & 1u;
+            unsigned TL[NC], TU[NC];
 #pragma unroll
-            for (int c = 0; c < NC; c++) TQ[c] = COMP2 - TP[c];
-            const bool isY = (lam >> b) & 1u;  // this lane holds old[j+H] and will hold new[2j+1]
+            for (int c = 0; c < NC; c++) {
+                TQ[c] = COMP2 - TP[c];
+                TL[c] = isY ? TQ[c] : TP[c];
+                TU[c] = isY ? TP[c] : TQ[c];
+            }
+            constexpr int XSEL = b == 0 ? 0xA0 : 0x44, YSEL = b == 0 ? 0xF5 : 0xEE;  // quad_perm [0,0,2,2]/[1,1,3,3], [0,1,0,1]/[2,3,2,3]
             static_for<NR>([&](auto I) {
                 constexpr int r0 = decltype(I)::value;
                 constexpr unsigned cr = cls_c<P, R>(rotl_c<NB>((unsigned)r0 << (LB + 1), PHI));
-                const u16x2 own = M[r0];
-                const u16x2 oth = dpp_xor<(b < 0 ? 0 : b)>(own);
-                const u16x2 a = madd<SAT>(own, as_v(TP[cr]));   // X: m0 = old[j]+t     Y: m3 = old[j+H]+t
-                const u16x2 q = madd<SAT>(oth, as_v(TQ[cr]));   // X: m1 = old[j+H]+t'  Y: m2 = old[j]+t'
-                const u16x2 lower = isY ? q : a, upper = isY ? a : q;
+                const u16x2 lo_src = dpp_quad<XSEL>(M[r0]);  // old[j]
+                const u16x2 up_src = dpp_quad<YSEL>(M[r0]);  // old[j+H]
+                const u16x2 lower = madd<SAT>(lo_src, as_v(TL[cr]));
+                const u16x2 upper = madd<SAT>(up_src, as_v(TU[cr]));
                 M[r0] = acs_pk<SAT, (r0 & 7) + 1>(lower, upper, acc[r0 >> 3]);
             });
         }
