@@ -119,7 +119,8 @@ def main():
     ap.add_argument("--chunk-frames", type=int, default=None, help="frames per handle (default: all, halved until the history fits)")
     ap.add_argument("--hbm-budget-gb", type=float, default=200.0, help="decision-history budget per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", action="store_true", help="also report value_pipelined: steps alternated over two handles/streams")
+    ap.add_argument("--pipeline", action="store_true", help="(default for K <= 15) also report value_pipelined: the same steps double-buffered over two handles")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the value_pipelined extra")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -202,10 +203,10 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, dev)
 
-    # Optional extra (not `value`): the same K steps issued alternately on two handles / two streams, so that the
-    # HBM-bound chainback of one batch overlaps the VALU-bound update of the next (steady-state serving throughput).
+    # Extra (never `value`): the same K steps double-buffered over two handles, so that the HBM-bound chainback of one
+    # batch overlaps the VALU-bound update of the next (steady-state serving throughput; +7 % for K=7 on one MI355X).
     pipelined = None
-    if args.pipeline and spec.K <= 15 and nchunks == 1:
+    if not args.no_pipeline and spec.K <= 15 and nchunks == 1 and 2 * chunk * dec_bytes_per_frame <= budget:
         # Two handles (two decision-history buffers).  All ACS updates go, in order, to one high-priority stream, so
         # the next update is dispatched first and spreads evenly over the CUs (exactly one wave per SIMD: a
         # chainback workgroup that got there first would make two update workgroups share a CU and double their
