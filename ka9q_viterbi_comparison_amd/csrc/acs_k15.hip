@@ -327,7 +327,7 @@ __global__ __launch_bounds__(THREADS, 2) void acs_k15_kernel(AcsK15Args a) {
                     unsigned words[4];
                     stage<SP, PHI>(M, sraw, tid, words);
 #pragma unroll
-                    for (int w = 0; w < 4; w++) drow[w * 128] = words[w];
+                    for (int w = 0; w < 4; w++) __builtin_nontemporal_store(words[w], drow + w * 128);  // written once, read much later
                     drow += 512;
                     if constexpr (SP) {
                         // spiral615.cpp:31-40,269: if new[0] > 74 subtract the minimum -- it fires on nearly every step,

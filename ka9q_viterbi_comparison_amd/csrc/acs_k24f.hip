@@ -250,9 +250,10 @@ __global__ __launch_bounds__(256) void acs_k24f_pass_kernel(const int16_t *oldm,
             unsigned acc[WPT];
             stage<G, PHI>(M, sy0, sy1, pt, acc);
             unsigned *row = reinterpret_cast<unsigned *>(rows + (size_t)S * (N / 8)) + (size_t)u * WPT;
-            if constexpr (WPT == 4) *reinterpret_cast<uint4 *>(row) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
-            else if constexpr (WPT == 2) *reinterpret_cast<uint2 *>(row) = make_uint2(acc[0], acc[1]);
-            else *row = acc[0];
+            // decision words are written once and read by the chainback much later: keep them out of the caches the
+            // 32 MiB of metrics live in
+#pragma unroll
+            for (int w = 0; w < WPT; w++) __builtin_nontemporal_store(acc[w], row + w);
             if (u == 0) {  // state 0 is position 0 in every phase: thread 0, register 0, low field
                 const int new0 = (int)(short)(as_u32(M[0]) & 0xffffu);
                 if (new0 >= Code224::renorm_thr && pending == 0) flags[K24F_PENDING] = pending = rel_row0 + S + 1;

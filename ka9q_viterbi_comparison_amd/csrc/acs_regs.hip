@@ -405,8 +405,10 @@ __device__ __forceinline__ void run_period(u16x2 (&M)[NR_], const unsigned (&cur
             S::template run<PHI>(M, sraw, lam, words);
 #pragma unroll
             for (int w = 0; w < DW; w++) {
-                if constexpr (G::WBYTES == 4) reinterpret_cast<unsigned *>(dp)[w * 64] = words[w];
-                else reinterpret_cast<unsigned short *>(dp)[w * 64] = (unsigned short)words[w];
+                // written once, read by the chainback much later: non-temporal stores keep the history from lingering
+                // dirty in L2 / the Infinity Cache (chainback right after the update: 0.219 -> 0.194 ms for K=7)
+                if constexpr (G::WBYTES == 4) __builtin_nontemporal_store(words[w], reinterpret_cast<unsigned *>(dp) + w * 64);
+                else __builtin_nontemporal_store((unsigned short)words[w], reinterpret_cast<unsigned short *>(dp) + w * 64);
             }
             dp += (long)DW * 64 * G::WBYTES;
         }
