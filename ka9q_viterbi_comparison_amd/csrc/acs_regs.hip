@@ -785,7 +785,7 @@ __global__ __launch_bounds__(64) void chainback_regs_lds_kernel(ChainbackRegsArg
 #pragma unroll
             for (int c = 0; c < GB / 1024; c++)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + c * 1024),
-                                                 (__attribute__((address_space(3))) void *)(ring + b * BUF + g * GB + c * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(ring + b * BUF + g * GB + c * 1024), 16, 0, 2);
         }
     };
 
@@ -890,7 +890,7 @@ __global__ __launch_bounds__(64) void chainback_k7_lds_kernel(ChainbackRegsArgs 
 #pragma unroll
         for (int c = 0; c < GB / 1024; c++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + c * 1024),
-                                             (__attribute__((address_space(3))) void *)(ring + b * GB + c * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(ring + b * GB + c * 1024), 16, 0, 2);
     };
     // cnt <= 64 rows below i, through LDS with a dependent read per row and the reference's byte stores
     auto slow_rows = [&](unsigned &i, unsigned cnt) {
