@@ -7,19 +7,21 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 // every block streams its own contiguous region (like one chainback wave walking its 1 MiB history), `per` uint4 per thread
-__global__ __launch_bounds__(256) void read_regions(const uint4 *__restrict__ in, unsigned *__restrict__ sink, long per) {
-    const uint4 *p = in + (long)blockIdx.x * per * blockDim.x + threadIdx.x;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ __launch_bounds__(256) void read_regions(const u32x4 *__restrict__ in, unsigned *__restrict__ sink, long per) {
+    const u32x4 *p = in + (long)blockIdx.x * per * blockDim.x + threadIdx.x;
     unsigned acc = 0;
 #pragma unroll 8
     for (long i = 0; i < per; i++) {
-        const uint4 q = p[i * blockDim.x];
+        const u32x4 q = NT ? __builtin_nontemporal_load(p + i * blockDim.x) : p[i * blockDim.x];
         acc ^= q.x ^ q.y ^ q.z ^ q.w;
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
 // one wave per block, global->LDS DMA in 12 KiB blocks, two in flight (the chainback_k7 pattern without the walk)
-template <bool BACK, bool STORES>
+template <bool BACK, bool STORES, int AUX = 0>
 __global__ __launch_bounds__(64) void read_dma(const unsigned char *__restrict__ in, unsigned *__restrict__ sink, long bytes_per_wave,
                                                unsigned char *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) unsigned char ring[3 * 12288];
@@ -29,7 +31,7 @@ __global__ __launch_bounds__(64) void read_dma(const unsigned char *__restrict__
 #pragma unroll
         for (int c = 0; c < 12; c++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (BACK ? nblk - 1 - n : n) * 12288 + c * 1024),
-                                             (__attribute__((address_space(3))) void *)(ring + b * 12288 + c * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(ring + b * 12288 + c * 1024), 16, 0, AUX);
     };
     issue(0, 0);
     if (nblk > 1) issue(1, 1);
@@ -68,12 +70,16 @@ int main() {
     for (int blocks : {1024, 2048, 4096, 16384}) {
         char nm[80]; snprintf(nm, sizeof nm, "vector loads, %d blocks x 256 thr, own region", blocks);
         const long per = (long)(bytes / 16 / ((size_t)blocks * 256));
-        timeit(nm, [&] { hipLaunchKernelGGL(read_regions, dim3(blocks), dim3(256), 0, 0, (const uint4 *)a, sink, per); });
+        timeit(nm, [&] { hipLaunchKernelGGL((read_regions<false>), dim3(blocks), dim3(256), 0, 0, (const u32x4 *)a, sink, per); });
+        snprintf(nm, sizeof nm, "  same, non-temporal loads");
+        timeit(nm, [&] { hipLaunchKernelGGL((read_regions<true>), dim3(blocks), dim3(256), 0, 0, (const u32x4 *)a, sink, per); });
     }
     for (int waves : {1024, 2048, 4096}) {
         char nm[80]; snprintf(nm, sizeof nm, "LDS DMA, %d single-wave blocks, 12 KiB x 2 in flight", waves);
         const long bpw = (long)(bytes / waves) / 12288 * 12288;
         timeit(nm, [&] { hipLaunchKernelGGL((read_dma<false, false>), dim3(waves), dim3(64), 0, 0, a, sink, bpw, outb); });
+        snprintf(nm, sizeof nm, "  same, non-temporal (aux = nt)");
+        timeit(nm, [&] { hipLaunchKernelGGL((read_dma<false, false, 2>), dim3(waves), dim3(64), 0, 0, a, sink, bpw, outb); });
         snprintf(nm, sizeof nm, "  same, blocks walked from the top down");
         timeit(nm, [&] { hipLaunchKernelGGL((read_dma<true, false>), dim3(waves), dim3(64), 0, 0, a, sink, bpw, outb); });
         snprintf(nm, sizeof nm, "  same, top down + 3 byte stores per block per lane");
