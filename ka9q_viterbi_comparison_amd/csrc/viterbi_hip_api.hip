@@ -72,10 +72,11 @@ struct vhip_decoder {
     int regs_lb = 0;           // REGS variant: log2(lanes per frame)
     vh::RegsLayout lay{};      // REGS variant: decision layout
     int frames_padded = 0;     // frames rounded up to a whole wave (both decision layouts fit the same buffer)
-    hipStream_t aux_stream[2] = {nullptr, nullptr};  // K=24 with several frames: two decodes in flight
-    int *h_pending = nullptr;                        // K=24: pinned copies of the renormalisation flag, [3 streams][2 batches]
+    static constexpr int K24_WORKERS = 3;            // K=24 with several frames: this many decodes in flight
+    hipStream_t aux_stream[K24_WORKERS] = {};
+    int *h_pending = nullptr;                        // K=24: pinned copies of the renormalisation flag, [1 + K24_WORKERS streams][2 batches]
     int *h_pending_dev = nullptr;                    //        the same words as the device addresses them
-    hipEvent_t k24_ev[3][2] = {};                    // K=24: "batch finished and its flag copy landed"
+    hipEvent_t k24_ev[1 + K24_WORKERS][2] = {};                    // K=24: "batch finished and its flag copy landed"
     size_t total_bytes = 0;
 };
 
@@ -331,20 +332,20 @@ vhip_decoder *vhip_create(int code, const int *poly, int len, int nframes) {
     const size_t met_bytes = (size_t)nframes * p->N * sizeof(int16_t) * (code == VHIP_KA9Q224 ? 2 : 1);
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&p->d_dec), dec_bytes ? dec_bytes : 16);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_metrics), met_bytes);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_flags), sizeof(int) * 16);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_flags), sizeof(int) * 32);
     if (e == hipSuccess) e = hipMemset(p->d_dec, 0, dec_bytes ? dec_bytes : 16);
-    if (e == hipSuccess) e = hipMemset(p->d_flags, 0, sizeof(int) * 16);
+    if (e == hipSuccess) e = hipMemset(p->d_flags, 0, sizeof(int) * 32);
     if (e != hipSuccess) {
         fail("create: device allocation", e);
         vhip_delete(p);
         return nullptr;
     }
     if (code == VHIP_KA9Q224 && nframes > 1)
-        for (int w = 0; w < 2 && e == hipSuccess; w++) e = hipStreamCreateWithFlags(&p->aux_stream[w], hipStreamNonBlocking);
+        for (int w = 0; w < vhip_decoder::K24_WORKERS && e == hipSuccess; w++) e = hipStreamCreateWithFlags(&p->aux_stream[w], hipStreamNonBlocking);
     if (code == VHIP_KA9Q224) {
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&p->h_pending), sizeof(int) * 6, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&p->h_pending), sizeof(int) * 2 * (1 + vhip_decoder::K24_WORKERS), hipHostMallocMapped);
         if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_pending_dev), p->h_pending, 0);
-        for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&p->k24_ev[i / 2][i % 2], hipEventDisableTiming);
+        for (int i = 0; i < 2 * (1 + vhip_decoder::K24_WORKERS) && e == hipSuccess; i++) e = hipEventCreateWithFlags(&p->k24_ev[i / 2][i % 2], hipEventDisableTiming);
     }
     if (e != hipSuccess) {
         fail("create: stream", e);
@@ -371,9 +372,9 @@ void vhip_delete(vhip_decoder *p) {
     if (p->d_dec) (void)hipFree(p->d_dec);
     if (p->d_metrics) (void)hipFree(p->d_metrics);
     if (p->d_flags) (void)hipFree(p->d_flags);
-    for (int w = 0; w < 2; w++)
+    for (int w = 0; w < vhip_decoder::K24_WORKERS; w++)
         if (p->aux_stream[w]) (void)hipStreamDestroy(p->aux_stream[w]);
-    for (int i = 0; i < 6; i++)
+    for (int i = 0; i < 2 * (1 + vhip_decoder::K24_WORKERS); i++)
         if (p->k24_ev[i / 2][i % 2]) (void)hipEventDestroy(p->k24_ev[i / 2][i % 2]);
     if (p->h_pending) (void)hipHostFree(p->h_pending);
     if (p->d_syms_stage) (void)hipFree(p->d_syms_stage);
@@ -455,11 +456,11 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
     if (p->code == VHIP_KA9Q224) {
         if (p->variant == VHIP_VARIANT_HBM_FUSED && p->nframes > 1) {
             // A single K=24 decode leaves the chip under-occupied between its load/compute/store phases (two concurrent
-            // decodes run 1.47x faster than two serial ones), so frames are decoded two at a time: two host threads,
-            // each with its own stream and flag words, frames interleaved between them.
+            // decodes run 1.47x faster than two serial ones), so K24_WORKERS frames are decoded at a time: one host thread
+            // each, with its own stream and flag words, frames interleaved between them.
             HIP_TRY(hipStreamSynchronize(p->stream));  // the caller's symbols are ready
-            constexpr int W = 2;
-            int rcs[W] = {0, 0};
+            constexpr int W = vhip_decoder::K24_WORKERS;
+            int rcs[W] = {};
             std::string errs[W];
             std::thread th[W];
             for (int w = 0; w < W; w++)
