@@ -131,9 +131,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the decode path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    # One rank per GPU.  VITERBI_BENCH_BACKEND=gloo is a rehearsal mode for a box with fewer GPUs than ranks: the ranks then
+    # share the visible devices and the (scalar) reductions run on CPU tensors; RCCL refuses two ranks on one device.
+    backend = os.environ.get("VITERBI_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     n_gpus = world
     if args.gpus != world and rank == 0:
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
@@ -148,7 +155,8 @@ def main():
     ebn0 = spec.ebn0_db if args.ebn0 is None else args.ebn0
 
     stream = torch.cuda.current_stream()
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
+    rdev = dev if backend == "nccl" else None  # where the scalar reductions live
     d_payload = torch.empty(frames * payload_bytes, dtype=torch.uint8, device=dev)
     d_syms = torch.empty(frames * nsteps * spec.R, dtype=torch.uint8, device=dev)
     d_out = torch.zeros(frames * payload_bytes, dtype=torch.uint8, device=dev)
@@ -201,7 +209,7 @@ def main():
         one_pass(events[i])
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, dev)
+    elapsed = max_over_ranks(elapsed, rdev)
 
     # Extra (never `value`): the same K steps double-buffered over two handles, so that the HBM-bound chainback of one
     # batch overlaps the VALU-bound update of the next (steady-state serving throughput; +7 % for K=7 on one MI355X).
@@ -239,7 +247,7 @@ def main():
         for k in range(args.steps):
             pass_on(k)
         barrier()
-        pipelined = max_over_ranks(time.perf_counter() - t0, dev)
+        pipelined = max_over_ranks(time.perf_counter() - t0, rdev)
         assert torch.equal(d_out, d_out2)
         dec.set_stream(stream.cuda_stream)
         dec2.close()
@@ -248,7 +256,7 @@ def main():
     cb_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
     # correctness guard outside the timed region: decoded bytes vs transmitted payload (BER over the batch)
     nerr = count_bit_errors_dev(d_out, d_payload, frames * payload_bytes, stream.cuda_stream) if spec.K != 24 else -1
-    nerr = sum_over_ranks(nerr, dev) if spec.K != 24 else -1
+    nerr = sum_over_ranks(nerr, rdev) if spec.K != 24 else -1
 
     if rank == 0:
         total_syms = frames * nsteps * spec.R * n_gpus
