@@ -7,9 +7,14 @@ HBM: init (reset metrics) + ACS update + chainback, exactly the three calls the 
 2048 info bits per GPU, AWGN soft symbols.  Frames are sharded across ranks (no data-path collective;
 torch.distributed is used only for the barrier and the max-over-ranks timing) -> "scaling": "weak".
 
+The steps are issued back to back on ONE handle.  For K <= 15 the handle is double-buffered inside the library
+(vhip_set_pipeline_depth(2): two decision-history buffers and two internal streams), so the HBM-bound chainback of
+step i overlaps the VALU-bound update of step i+1; --pipeline-depth 1 gives the strictly serial schedule.
+
 metric / value: coded symbols (incl. tail, the reference's definition scripts/tabulate_data.py:33) decoded per
 second over the whole job, Msymbols/s.  The JSON line also carries the ACS-update-only and chainback-only
-rates from HIP events, the HBM roofline of the dominant (ACS) kernel, and a CPU baseline timed on this host.
+rates from HIP events recorded by the library on the streams its kernels run on (vhip_enable_timing), the HBM
+roofline of the dominant (ACS) kernel, and a CPU baseline timed on this host.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -30,10 +35,14 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from ka9q_viterbi_comparison_amd import HipViterbi, codes as C, count_bit_errors_dev, gen_frames_dev, noise_q12  # noqa: E402
+from ka9q_viterbi_comparison_amd import VARIANT_HBM, VARIANT_HBM_FUSED, VARIANT_LDS, VARIANT_REGS  # noqa: E402
 from ka9q_viterbi_comparison_amd.decoder import gen_frames_host  # noqa: E402
-from ka9q_viterbi_comparison_amd.sharding import barrier as shard_barrier, max_over_ranks, sum_over_ranks, weak_range  # noqa: E402
+from ka9q_viterbi_comparison_amd.sharding import run_sharded_job  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from kernel_hash import kernel_family, kernel_source_hash  # noqa: E402
 
 
 def algorithmic_bytes_per_frame_step(spec):
@@ -42,6 +51,18 @@ def algorithmic_bytes_per_frame_step(spec):
     if spec.K == 24:
         return 2 * (1 << 23) * 2 + (1 << 23) // 8 + 2
     return spec.R + (1 << (spec.K - 1)) // 8
+
+
+def moved_bytes_per_frame_step(spec, variant, k24_passes_per_period=None):
+    """Bytes the ACS kernels really move per frame-step.  K <= 15: the algorithmic figure (metrics stay on chip; the PMC
+    traffic confirms 1.02x).  K=24: the multi-step passes move the 16 MiB metric array twice per PASS, not per step:
+    passes_per_23_steps x 32 MiB + 23 x (1 MiB row + 2 symbol bytes), per 23 steps."""
+    if spec.K != 24:
+        return float(algorithmic_bytes_per_frame_step(spec))
+    if variant == VARIANT_HBM:
+        return float(algorithmic_bytes_per_frame_step(spec))
+    passes = k24_passes_per_period or 5
+    return (passes * 2 * (1 << 24) + 23 * ((1 << 20) + 2)) / 23.0
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -104,6 +125,99 @@ def cpu_baseline(spec, payload_bits, budget_s=12.0):
     }
 
 
+# ------------------------------------------------------------------------------------------------ the HIP shard
+class HipShard:
+    """This rank's frames, resident in HBM, and the handle that decodes them (the object run_sharded_job drives)."""
+
+    def __init__(self, args, spec, dev, frame_lo, frames):
+        self.args, self.spec, self.dev, self.frames = args, spec, dev, frames
+        self.stream = torch.cuda.current_stream()
+        defaults = {7: 2048, 9: 2048, 15: 2048, 24: 2048}
+        self.payload_bits = args.payload_bits or defaults[spec.K]
+        self.payload_bytes = self.payload_bits // 8
+        self.nsteps = self.payload_bits + spec.K - 1
+        self.ebn0 = spec.ebn0_db if args.ebn0 is None else args.ebn0
+        R = spec.R
+        self.d_payload = torch.empty(frames * self.payload_bytes, dtype=torch.uint8, device=dev)
+        self.d_syms = torch.empty(frames * self.nsteps * R, dtype=torch.uint8, device=dev)
+        if args.hard:
+            amp_q16, nq = C.HARD_AMP_Q16, 0
+        else:
+            amp_q16, nq = C.SOFT_AMP_Q16, noise_q12(R, C.SOFT_AMP, self.ebn0)
+        # synthetic frames generated on the device, distinct per rank (global frame ids frame_lo ...)
+        gen_frames_dev(spec, 0x5EED, frame_lo, frames, self.payload_bytes, amp_q16, nq, self.d_payload, self.d_syms, self.stream.cuda_stream)
+        # The decision history (N/8 bytes per frame-step, times the pipeline depth) must fit in HBM next to the symbols:
+        # large K=15 batches are decoded in chunks of frames that reuse one handle (SURVEY.md §7 "K=15 capacity"); a
+        # step still covers all frames.
+        self.depth = 1 if spec.K == 24 else max(1, args.pipeline_depth)
+        dec_bytes_per_frame = (self.nsteps + spec.K) * ((1 << (spec.K - 1)) // 8) * self.depth
+        budget = int(args.hbm_budget_gb * 1e9)
+        chunk = frames if args.chunk_frames is None else min(args.chunk_frames, frames)
+        while chunk > 64 and chunk * dec_bytes_per_frame > budget:
+            chunk = (chunk + 1) // 2
+        assert frames % chunk == 0, "frames must be a multiple of the chunk size"
+        self.chunk, self.nchunks = chunk, frames // chunk
+        self.dec = HipViterbi(args.code, self.nsteps, nframes=chunk, variant=args.variant, stream=self.stream.cuda_stream,
+                              pipeline_depth=self.depth)
+        self.dec.enable_timing(True)
+        # K=24's own chainback call convention needs nbits+K-1 to decode correctly (SURVEY.md §0.4); the harness call
+        # (nbits = payload bits) is what is timed, as in the reference.
+        self.cb_bits = self.payload_bits
+        # consecutive decodes of a pipelined handle need different output buffers: passes alternate between two
+        nout = 2 if self.depth > 1 else 1
+        self.d_out = [torch.zeros(frames * self.payload_bytes, dtype=torch.uint8, device=dev) for _ in range(nout)]
+        self.timed_from = None
+
+    def one_pass(self, i):
+        sc, oc = self.chunk * self.nsteps * self.spec.R, self.chunk * self.payload_bytes
+        out = self.d_out[i % len(self.d_out)]
+        for c in range(self.nchunks):
+            self.dec.reset()
+            self.dec.update(self.d_syms[c * sc:(c + 1) * sc], nbits=self.nsteps)
+            self.dec.chainback(self.cb_bits, out=out[c * oc:(c + 1) * oc])
+
+    def drain(self):
+        self.dec.join()
+        if self.timed_from is None:
+            self.dec.read_timing()  # discard the warm-up launches: what is read in stats() is the timed region only
+            self.timed_from = True
+
+    def stats(self):
+        su, nu, sc, nc = self.dec.read_timing()
+        passes = max(1, nu // self.nchunks)
+        nerr = -1
+        if self.spec.K != 24:
+            errs = [count_bit_errors_dev(o, self.d_payload, self.frames * self.payload_bytes, self.stream.cuda_stream) for o in self.d_out]
+            assert len(set(errs)) == 1 and all(torch.equal(self.d_out[0], o) for o in self.d_out), "passes disagree"
+            nerr = errs[0]
+        return {
+            "units_per_pass": self.frames * self.nsteps * self.spec.R,
+            "bit_errors": nerr,
+            "update_ms": su / passes,          # per pass (all chunks), kernels only, on the stream they ran on
+            "chainback_ms": sc / passes,
+            "timed_update_launches": nu,
+            "variant": self.dec.variant,
+        }
+
+    def close(self):
+        self.dec.close()
+
+
+def replayed_counter(kind, code, family):
+    """profiles/<kind>_<code>.json from a committed rocprofv3 --pmc pass: quoted only while the kernel sources it was taken
+    on are unchanged (hash recorded by tools/summarize_pmc.py / summarize_valu.py); otherwise None + reason."""
+    path = os.path.join(ROOT, "profiles", f"{kind}_{code}.json")
+    if not os.path.exists(path):
+        return None, "no committed PMC pass"
+    try:
+        v = json.load(open(path))
+    except Exception as e:  # noqa: BLE001
+        return None, f"unreadable: {e}"
+    if v.get("kernel_source_sha256") != kernel_source_hash(family):
+        return None, f"stale: {os.path.relpath(path, ROOT)} was taken on other kernel sources"
+    return v, f"replayed from {os.path.relpath(path, ROOT)} (rocprofv3 --pmc, sources {v.get('kernel_source_sha256')}); not measured in this run"
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -119,11 +233,12 @@ def main():
     ap.add_argument("--chunk-frames", type=int, default=None, help="frames per handle (default: all, halved until the history fits)")
     ap.add_argument("--hbm-budget-gb", type=float, default=200.0, help="decision-history budget per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", action="store_true", help="(default for K <= 15) also report value_pipelined: the same steps double-buffered over two handles")
-    ap.add_argument("--no-pipeline", action="store_true", help="skip the value_pipelined extra")
-    ap.add_argument("--pipeline-priority", action="store_true", help="value_pipelined with the priority-stream scheme instead of two unordered streams")
+    ap.add_argument("--pipeline-depth", type=int, default=2, help="decision-history buffers behind the handle (K<=15): 2 = double-buffered (default), 1 = strictly serial")
+    ap.add_argument("--no-pipeline", action="store_true", help="same as --pipeline-depth 1")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
+    if args.no_pipeline:
+        args.pipeline_depth = 1
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -142,192 +257,82 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    n_gpus = world
     if args.gpus != world and rank == 0:
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
     spec = C.CODES[args.code]
     # BASELINE.json configs: K=7 x 65536 frames, K=15 x 4096 frames, K=24 single long frame; K=9 sized in between
-    defaults = {7: (65536, 2048), 9: (32768, 2048), 15: (4096, 2048), 24: (1, 2048)}
-    frames = args.frames or defaults[spec.K][0]
-    payload_bits = args.payload_bits or defaults[spec.K][1]
-    payload_bytes = payload_bits // 8
-    nsteps = payload_bits + spec.K - 1
-    ebn0 = spec.ebn0_db if args.ebn0 is None else args.ebn0
-
-    stream = torch.cuda.current_stream()
+    default_frames = {7: 65536, 9: 32768, 15: 4096, 24: 1}
+    frames = args.frames or default_frames[spec.K]
     dev = torch.device("cuda", dev_index)
     rdev = dev if backend == "nccl" else None  # where the scalar reductions live
-    d_payload = torch.empty(frames * payload_bytes, dtype=torch.uint8, device=dev)
-    d_syms = torch.empty(frames * nsteps * spec.R, dtype=torch.uint8, device=dev)
-    d_out = torch.zeros(frames * payload_bytes, dtype=torch.uint8, device=dev)
-    if args.hard:
-        amp_q16, nq = C.HARD_AMP_Q16, 0
-    else:
-        amp_q16, nq = C.SOFT_AMP_Q16, noise_q12(spec.R, C.SOFT_AMP, ebn0)
-    # synthetic frames generated on the device, distinct per rank (frame ids rank*frames ...)
-    frame_lo, _ = weak_range(frames, rank)
-    gen_frames_dev(spec, 0x5EED, frame_lo, frames, payload_bytes, amp_q16, nq, d_payload, d_syms, stream.cuda_stream)
-    # The decision history (N/8 bytes per frame-step) must fit in HBM next to the symbols: large K=15 batches are
-    # decoded in chunks of frames that reuse one handle (SURVEY.md §7 "K=15 capacity"); a step still covers all frames.
-    dec_bytes_per_frame = (nsteps + spec.K) * ((1 << (spec.K - 1)) // 8)
-    budget = int(args.hbm_budget_gb * 1e9)
-    chunk = frames if args.chunk_frames is None else args.chunk_frames
-    while chunk > 64 and chunk * dec_bytes_per_frame > budget:
-        chunk = (chunk + 1) // 2
-    nchunks = (frames + chunk - 1) // chunk
-    assert frames % chunk == 0, "frames must be a multiple of the chunk size"
-    dec = HipViterbi(args.code, nsteps, nframes=chunk, variant=args.variant, stream=stream.cuda_stream)
-    # K=24's own chainback call convention needs nbits+K-1 to decode correctly; the harness call
-    # (nbits = payload bits) is what is timed, as in the reference.
-    cb_bits = payload_bits
-    sym_chunk, out_chunk = chunk * nsteps * spec.R, chunk * payload_bytes
+    holder = {}
 
-    def one_pass(ev=None):
-        for c in range(nchunks):
-            first, last = c == 0, c == nchunks - 1
-            dec.reset()
-            if ev and first:
-                ev[0].record(stream)
-            dec.update(d_syms[c * sym_chunk:(c + 1) * sym_chunk], nbits=nsteps)
-            if ev and nchunks == 1:
-                ev[1].record(stream)
-            dec.chainback(cb_bits, out=d_out[c * out_chunk:(c + 1) * out_chunk])
-            if ev and last:
-                if nchunks > 1:
-                    ev[1].record(stream)  # chunked: per-kernel split not available, report the whole pass as update
-                ev[2].record(stream)
+    def make_shard(frame_lo, nframes):
+        holder["shard"] = HipShard(args, spec, dev, frame_lo, nframes)
+        return holder["shard"]
 
-    def barrier():
-        shard_barrier(dev)
-
-    for _ in range(args.warmup):
-        one_pass()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_pass(events[i])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, rdev)
-
-    # Extra (never `value`): the same K steps double-buffered over two handles, so that the HBM-bound chainback of one
-    # batch overlaps the VALU-bound update of the next (steady-state serving throughput; +20 % for K=7 on one MI355X).
-    pipelined = None
-    if not args.no_pipeline and spec.K <= 15 and nchunks == 1 and 2 * chunk * dec_bytes_per_frame <= budget:
-        # Two handles (two decision-history buffers).  All ACS updates go, in order, to one high-priority stream, so
-        # the next update is dispatched first and spreads evenly over the CUs (exactly one wave per SIMD: a
-        # chainback workgroup that got there first would make two update workgroups share a CU and double their
-        # time); every chainback goes to a normal-priority stream behind an event and fills in beside the next update.
-        hi = torch.cuda.Stream(device=dev, priority=-1)
-        lo = torch.cuda.Stream(device=dev, priority=0)
-        dec2 = HipViterbi(args.code, nsteps, nframes=frames, variant=args.variant, stream=hi.cuda_stream)
-        d_out2 = torch.zeros_like(d_out)
-        lanes = [(dec, d_out), (dec2, d_out2)]
-        cb_done = [None, None]
-        torch.cuda.synchronize()
-
-        free_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-
-        def pass_on(k):
-            dk, ok = lanes[k & 1]
-            if not args.pipeline_priority:
-                # default: two independent in-order streams, no cross-stream ordering at all -- the two decodes drift apart
-                # and one's chainback / launch ramps fill the other's update (K=7: +20 %; the priority scheme below: +4 %)
-                dk.set_stream(free_streams[k & 1].cuda_stream)
-                dk.reset()
-                dk.update(d_syms, nbits=nsteps)
-                dk.chainback(cb_bits, out=ok)
-                return
-            if cb_done[k & 1] is not None:
-                hi.wait_event(cb_done[k & 1])  # this handle's previous history has been walked
-            dk.set_stream(hi.cuda_stream)
-            dk.reset()
-            dk.update(d_syms, nbits=nsteps)
-            upd_done = hi.record_event()
-            lo.wait_event(upd_done)
-            dk.set_stream(lo.cuda_stream)
-            dk.chainback(cb_bits, out=ok)
-            cb_done[k & 1] = lo.record_event()
-
-        for k in range(2):
-            pass_on(k)
-        barrier()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            pass_on(k)
-        barrier()
-        pipelined = max_over_ranks(time.perf_counter() - t0, rdev)
-        assert torch.equal(d_out, d_out2)
-        dec.set_stream(stream.cuda_stream)
-        dec2.close()
-
-    upd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
-    cb_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
-    # correctness guard outside the timed region: decoded bytes vs transmitted payload (BER over the batch)
-    nerr = count_bit_errors_dev(d_out, d_payload, frames * payload_bytes, stream.cuda_stream) if spec.K != 24 else -1
-    nerr = sum_over_ranks(nerr, rdev) if spec.K != 24 else -1
+    core = run_sharded_job(make_shard, frames_per_rank=frames, steps=args.steps, warmup=args.warmup, rank=rank, world=world,
+                           device=dev, reduce_device=rdev)
+    shard = holder["shard"]
 
     if rank == 0:
-        total_syms = frames * nsteps * spec.R * n_gpus
-        ms_per_step = elapsed / args.steps * 1e3
-        value = total_syms * args.steps / elapsed / 1e6
-        abytes = algorithmic_bytes_per_frame_step(spec) * frames * nsteps  # per launch (one rank)
-        achieved = abytes / (upd_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.code}.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        st = core.pop("stats")
+        n_gpus, nsteps, payload_bits = core["n_gpus"], shard.nsteps, shard.payload_bits
+        upd_ms, cb_ms = st["update_ms"], st["chainback_ms"]
+        variant = st["variant"]
+        family = kernel_family(spec.K)
+        abytes = algorithmic_bytes_per_frame_step(spec) * frames * nsteps  # per pass of one rank
+        mbytes = moved_bytes_per_frame_step(spec, variant, getattr(shard.dec, "k24_passes_per_period", None)) * frames * nsteps
+        achieved = mbytes / (upd_ms * 1e-3) / 1e9
+        tv, tsrc = replayed_counter("traffic", args.code, family)
+        vv, vsrc = replayed_counter("valu", args.code, family)
         valu = None
-        vpath = os.path.join(ROOT, "profiles", f"valu_{args.code}.json")
-        if os.path.exists(vpath):
-            try:
-                v = json.load(open(vpath))
-                # instructions per launch come from the committed PMC pass; the time is this run's
-                valu = {"wave_instr_per_launch": v["valu_wave_instr_per_launch"],
-                        "achieved_ginstr_per_s": round(v["valu_wave_instr_per_launch"] / (upd_ms * 1e-3) / 1e9, 2),
-                        "issue_ceiling_ginstr_per_s": round(v["issue_ceiling_ginstr_per_s"], 2),
-                        "frac": round(v["valu_wave_instr_per_launch"] / (upd_ms * 1e-3) / 1e9 / v["issue_ceiling_ginstr_per_s"], 4)}
-            except Exception:
-                valu = None
+        if vv is not None:
+            # instructions per launch come from the committed PMC pass; the time is this run's
+            rate = vv["valu_wave_instr_per_launch"] / (upd_ms * 1e-3) / 1e9
+            valu = {"wave_instr_per_launch": vv["valu_wave_instr_per_launch"], "achieved_ginstr_per_s": round(rate, 2),
+                    "issue_ceiling_ginstr_per_s": round(vv["issue_ceiling_ginstr_per_s"], 2),
+                    "frac": round(rate / vv["issue_ceiling_ginstr_per_s"], 4), "source": vsrc}
         out = {
             "metric": f"Msymbols/s decoded, K={spec.K} r=1/{spec.R} (init + ACS update + chainback)",
-            "value": round(value, 6),
+            "value": round(core["value"] / 1e6, 6),
             "unit": "Msymbols/s",
             "n_gpus": n_gpus,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4),
+            "steps": core["steps"],
+            "warmup": core["warmup"],
+            "ms_per_step": round(core["ms_per_step"], 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8" if spec.family != "ka9q-i16-sat" else "i16",
-            "data": "synthetic" + (" hard 0/255 symbols" if args.hard else f" AWGN Eb/N0={ebn0} dB, amplitude {C.SOFT_AMP}") + ", generated on device",
+            "data": "synthetic" + (" hard 0/255 symbols" if args.hard else f" AWGN Eb/N0={shard.ebn0} dB, amplitude {C.SOFT_AMP}") + ", generated on device",
             "config": {"workload": f"viterbi{spec.name}: K={spec.K} r=1/{spec.R}, {frames} frames/GPU x {payload_bits} info bits "
                                    f"({nsteps} trellis steps, {nsteps * spec.R} symbols/frame)",
-                       "frames_per_gpu": frames, "chunk_frames": chunk, "payload_bits": payload_bits, "variant": dec.variant,
+                       "frames_per_gpu": frames, "chunk_frames": shard.chunk, "payload_bits": payload_bits, "variant": variant,
+                       "pipeline_depth": shard.depth,
                        "parallelism": f"frame-shard x{n_gpus}, no collective"},
             "update_msym_s": round(frames * nsteps * spec.R * n_gpus / (upd_ms * 1e-3) / 1e6, 6),
-            "chainback_mbit_s": round(frames * cb_bits * n_gpus / (cb_ms * 1e-3) / 1e6, 3),
+            "chainback_mbit_s": round(frames * shard.cb_bits * n_gpus / (cb_ms * 1e-3) / 1e6, 3),
             "update_ms": round(upd_ms, 4),
             "chainback_ms": round(cb_ms, 4),
-            "bit_errors": int(nerr),
-            "value_pipelined": (round(total_syms * args.steps / pipelined / 1e6, 3) if pipelined else None),
+            "kernel_timing": "HIP events recorded by the library around its launches, on the streams they run on, timed region only"
+                             + ("; update and chainback of consecutive steps overlap (pipeline depth 2), so the two do not add up to ms_per_step" if shard.depth > 1 else ""),
+            "bit_errors": int(core["bit_errors"]),
             "payload_bits_total": frames * payload_bits * n_gpus,
+            # achieved = bytes the ACS kernels move per pass / their event-timed duration; for K <= 15 that IS the
+            # algorithmic figure of SURVEY.md §8d, for the multi-step K=24 passes it is what the passes really move
             "roofline": {"bound": "hbm", "kernel": "acs_update", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": abytes},
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": (tv or {}).get("hbm_bytes_per_launch"), "traffic_source": tsrc,
+                         "bytes_per_launch": int(mbytes), "algorithmic_bytes_per_launch": int(abytes)},
             # the binding limit of the K<=15 ACS kernels: packed-integer VALU issue, not HBM
             "valu_issue": valu,
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, payload_bits, args.cpu_budget)
         print(json.dumps(out), flush=True)
-    dec.close()
+    shard.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -78,7 +78,8 @@ bool parse(int argc, char **argv, Args &a) {
         else { fprintf(stderr, "unknown argument %s\n", k.c_str()); return false; }
     }
     // same validation as src/main.cpp:344-351
-    if (a.sampling_time < 0.0f) { fprintf(stderr, "Sampling time must be positive (%.3f)\n", a.sampling_time); return false; }
+    if (a.sampling_time <= 0.0f) { fprintf(stderr, "Sampling time must be positive (%.3f)\n", a.sampling_time); return false; }
+    if (a.minimum_samples == 0) { fprintf(stderr, "Minimum number of samples must be non-zero\n"); return false; }
     return true;
 }
 

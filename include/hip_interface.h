@@ -47,8 +47,10 @@ public:
         check(vhip_update(m_handle, sym, static_cast<int>(per_frame / R)), "update");
     }
     void chainback(std::uint8_t *data, std::size_t total_bits) {
-        // ka9q615 returns a path metric here (viterbi615_sse2.cpp:90); like the reference adapter we ignore it
+        // ka9q615 returns a path metric here (viterbi615_sse2.cpp:90), any int: like the reference adapter we ignore the
+        // value, but a failed GPU chainback must not hand back stale bytes silently -- the status is separate
         (void)vhip_chainback(m_handle, data, static_cast<unsigned>(total_bits), 0u);
+        check(vhip_status(m_handle), "chainback");
     }
 
     // -- device-resident variants (asynchronous on the handle's stream)
@@ -57,6 +59,10 @@ public:
     void chainback_device(std::uint8_t *d_data, std::size_t total_bits) {
         check(vhip_chainback_dev(m_handle, d_data, static_cast<unsigned>(total_bits), 0u), "chainback_dev");
     }
+    // double-buffered decodes: reset() starts a new decode on the next history buffer; join() orders the outputs on the stream
+    void set_pipeline_depth(int depth) { check(vhip_set_pipeline_depth(m_handle, depth), "set_pipeline_depth"); }
+    void reset_device() { check(vhip_init(m_handle, 0), "init"); }
+    void join() { check(vhip_join(m_handle), "join"); }
     void sync() { check(vhip_sync(m_handle), "sync"); }
     int frames() const { return m_nframes; }
     vhip_decoder *handle() { return m_handle; }
@@ -75,3 +81,7 @@ using hip_viterbi615 = hip_viterbi_decoder<VHIP_KA9Q615, 15, 6>;
 using hip_viterbi224 = hip_viterbi_decoder<VHIP_KA9Q224, 24, 2>;
 using hip_spiral47 = hip_viterbi_decoder<VHIP_SPIRAL47, 7, 4>;
 using hip_spiral49 = hip_viterbi_decoder<VHIP_SPIRAL49, 9, 4>;
+// the remaining spiral arithmetic variants of src/main.cpp:370,388,408 (test_spiral<...> lines)
+using hip_spiral27 = hip_viterbi_decoder<VHIP_SPIRAL27, 7, 2>;
+using hip_spiral29 = hip_viterbi_decoder<VHIP_SPIRAL29, 9, 2>;
+using hip_spiral615 = hip_viterbi_decoder<VHIP_SPIRAL615, 15, 6>;

@@ -66,6 +66,29 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits);
 int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbits, unsigned int endstate);
 void vhip_delete(vhip_decoder *p);
 
+/* Error status of the last init / update / chainback on the handle: 0 = succeeded, -1 = failed (message in
+ * vhip_last_error()).  The reference ABI cannot carry it: update_*_blk returns void, and chainback_viterbi615 returns
+ * the end state's path metric (viterbi615_sse2.cpp:76,90), which may be any int, -1 included. */
+int vhip_status(const vhip_decoder *p);
+
+/* Pipelined decodes (additive).  depth = 2 (or 3) gives the handle that many {decision history, path metrics} sets and
+ * internal streams; every vhip_init() starts a new decode on the next set, so init / update / chainback issued back to
+ * back for decode i+1 overlap the (HBM-bound) chainback of decode i with the (VALU-bound) update of decode i+1.
+ * Ordering: each device-pointer call is ordered BEHIND what the caller has enqueued on the handle's stream so far (its
+ * symbols are ready); the decoded bytes are ordered on the handle's stream only by vhip_join() (device-side wait, the host
+ * does not block) or vhip_sync().  Consecutive decodes must be given different output buffers.  depth can be set once,
+ * before the first update; K=24 handles do not take it (they keep several frames in flight by themselves).
+ * HBM cost: depth x the decision history (vhip_device_bytes). */
+int vhip_set_pipeline_depth(vhip_decoder *p, int depth);
+int vhip_get_pipeline_depth(const vhip_decoder *p);
+int vhip_join(vhip_decoder *p);
+
+/* Live kernel timing.  When enabled, every vhip_update_dev / vhip_chainback_dev is bracketed by HIP events on the stream
+ * its kernels run on (the handle's stream, or the internal stream of the current pipeline slot).  vhip_read_timing waits
+ * for the handle to go idle and returns the summed durations (ms) and launch counts since the previous read. */
+int vhip_enable_timing(vhip_decoder *p, int on);
+int vhip_read_timing(vhip_decoder *p, double *update_ms_sum, int *n_update, double *chainback_ms_sum, int *n_chainback);
+
 /* Stream / device plumbing.  `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
  * NULL selects the device's default stream. */
 int vhip_set_stream(vhip_decoder *p, void *stream);

@@ -51,6 +51,12 @@ SYMBOLS = [
     ("vhip_sync", C.c_int, [C.c_void_p]),
     ("vhip_device_count", C.c_int, []),
     ("vhip_last_error", C.c_char_p, []),
+    ("vhip_status", C.c_int, [C.c_void_p]),
+    ("vhip_enable_timing", C.c_int, [C.c_void_p, C.c_int]),
+    ("vhip_read_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    ("vhip_set_pipeline_depth", C.c_int, [C.c_void_p, C.c_int]),
+    ("vhip_get_pipeline_depth", C.c_int, [C.c_void_p]),
+    ("vhip_join", C.c_int, [C.c_void_p]),
     ("vhip_set_variant", C.c_int, [C.c_void_p, C.c_int]),
     ("vhip_get_variant", C.c_int, [C.c_void_p]),
     ("vhip_read_decision_rows", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/viterbi_hip.h"
@@ -30,6 +31,7 @@ void gen_frames_host(int K, int R, const int *poly, uint64_t seed, uint64_t fram
 namespace {
 
 thread_local std::string g_last_error;
+thread_local unsigned g_fail_count = 0;
 
 int fail(const char *what, hipError_t e = hipSuccess) {
     char buf[512];
@@ -38,6 +40,7 @@ int fail(const char *what, hipError_t e = hipSuccess) {
     else
         snprintf(buf, sizeof(buf), "viterbi_hip: %s", what);
     g_last_error = buf;
+    g_fail_count++;
     if (getenv("VHIP_VERBOSE")) fprintf(stderr, "%s\n", buf);
     return -1;
 }
@@ -78,9 +81,40 @@ struct vhip_decoder {
     int *h_pending_dev = nullptr;                    //        the same words as the device addresses them
     hipEvent_t k24_ev[1 + K24_WORKERS][2] = {};                    // K=24: "batch finished and its flag copy landed"
     size_t total_bytes = 0;
+    // Pipelined decodes (vhip_set_pipeline_depth): `depth` sets of {decision history, metrics, internal stream}.
+    // d_dec / d_metrics / pos above always describe the CURRENT set; vhip_init() rotates to the next one.
+    struct Slot {
+        unsigned char *d_dec = nullptr;
+        int16_t *d_metrics = nullptr;
+        int pos = 0;
+        hipStream_t stream = nullptr;  // internal, non-blocking
+        hipEvent_t done = nullptr;     // last work enqueued on `stream` (recorded by vhip_join)
+    };
+    static constexpr int MAX_DEPTH = 3;
+    Slot slots[MAX_DEPTH];
+    int depth = 1, cur_slot = 0;
+    hipEvent_t ev_input = nullptr;     // "the caller's stream has reached this call" (inputs are ready)
+    int status = 0;                    // 0, or -1 after a failed call on this handle (vhip_status)
+    // live kernel timing (vhip_enable_timing): event pairs around the update / chainback launches, on the stream they run on
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;                        // timing-enabled events, reused
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> t_upd, t_cb;  // recorded, not yet read
+    hipStream_t run_stream() const { return depth > 1 ? slots[cur_slot].stream : stream; }
 };
 
 namespace {
+
+// vhip_status(): -1 after a failed init / update / chainback on the handle, 0 after a successful one.  The reference ABI
+// returns void from update and a path metric (any int) from chainback_viterbi615, so the return value alone cannot
+// carry an error there.
+struct StatusScope {
+    vhip_decoder *p;
+    unsigned before;
+    explicit StatusScope(vhip_decoder *h) : p(h), before(g_fail_count) {}
+    ~StatusScope() {
+        if (p) p->status = g_fail_count != before ? -1 : 0;
+    }
+};
 
 int init_all_of(int code) {
     switch (code) {
@@ -121,6 +155,40 @@ int ensure_stage(unsigned char **buf, size_t *cap, size_t need, size_t *total) {
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(buf), need));
     *cap = need;
     *total += need;
+    return 0;
+}
+
+// Pipelined handles: work of the current decode runs on the slot's internal stream, ordered behind whatever the caller
+// has enqueued on the handle's stream so far (its symbols / output buffers are ready).
+int order_behind_caller(vhip_decoder *p) {
+    if (p->depth <= 1) return 0;
+    HIP_TRY(hipEventRecord(p->ev_input, p->stream));
+    HIP_TRY(hipStreamWaitEvent(p->run_stream(), p->ev_input, 0));
+    return 0;
+}
+// timing bracket: returns the event to record after the launches (nullptr when timing is off)
+hipEvent_t timing_begin(vhip_decoder *p, std::vector<std::pair<hipEvent_t, hipEvent_t>> &list, hipStream_t st) {
+    if (!p->timing) return nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; i++) {
+        if (!p->ev_pool.empty()) {
+            ev[i] = p->ev_pool.back();
+            p->ev_pool.pop_back();
+        } else if (hipEventCreate(&ev[i]) != hipSuccess) {
+            return nullptr;
+        }
+    }
+    if (hipEventRecord(ev[0], st) != hipSuccess) return nullptr;
+    list.emplace_back(ev[0], ev[1]);
+    return ev[1];
+}
+void timing_end(hipEvent_t e1, hipStream_t st) {
+    if (e1) (void)hipEventRecord(e1, st);
+}
+
+int sync_all(vhip_decoder *p) {
+    for (int i = 0; i < p->depth && p->depth > 1; i++) HIP_TRY(hipStreamSynchronize(p->slots[i].stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
     return 0;
 }
 
@@ -369,8 +437,22 @@ vhip_decoder *vhip_create(int code, const int *poly, int len, int nframes) {
 void vhip_delete(vhip_decoder *p) {
     if (!p) return;  // delete(NULL) is a no-op in the reference too (viterbi27_sse2.cpp:108-115)
     (void)use_device(p);
-    if (p->d_dec) (void)hipFree(p->d_dec);
-    if (p->d_metrics) (void)hipFree(p->d_metrics);
+    if (p->depth > 1) {
+        for (int i = 0; i < p->depth; i++) {
+            if (p->slots[i].stream) (void)hipStreamSynchronize(p->slots[i].stream);
+            if (p->slots[i].d_dec) (void)hipFree(p->slots[i].d_dec);
+            if (p->slots[i].d_metrics) (void)hipFree(p->slots[i].d_metrics);
+            if (p->slots[i].stream) (void)hipStreamDestroy(p->slots[i].stream);
+            if (p->slots[i].done) (void)hipEventDestroy(p->slots[i].done);
+        }
+    } else {
+        if (p->d_dec) (void)hipFree(p->d_dec);
+        if (p->d_metrics) (void)hipFree(p->d_metrics);
+    }
+    if (p->ev_input) (void)hipEventDestroy(p->ev_input);
+    for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
+    for (auto &pr : p->t_upd) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto &pr : p->t_cb) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (p->d_flags) (void)hipFree(p->d_flags);
     for (int w = 0; w < vhip_decoder::K24_WORKERS; w++)
         if (p->aux_stream[w]) (void)hipStreamDestroy(p->aux_stream[w]);
@@ -391,7 +473,86 @@ int vhip_set_stream(vhip_decoder *p, void *stream) {
 int vhip_sync(vhip_decoder *p) {
     if (!p) return fail("sync: NULL handle");
     if (use_device(p) != 0) return -1;
+    return sync_all(p);
+}
+
+int vhip_status(const vhip_decoder *p) { return p ? p->status : -1; }
+
+int vhip_enable_timing(vhip_decoder *p, int on) {
+    if (!p) return fail("enable_timing: NULL handle");
+    p->timing = on != 0;
+    return 0;
+}
+
+int vhip_read_timing(vhip_decoder *p, double *update_ms_sum, int *n_update, double *chainback_ms_sum, int *n_chainback) {
+    if (!p) return fail("read_timing: NULL handle");
+    if (use_device(p) != 0) return -1;
+    if (sync_all(p) != 0) return -1;
+    double su = 0.0, sc = 0.0;
+    for (auto &pr : p->t_upd) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+        su += ms;
+    }
+    for (auto &pr : p->t_cb) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+        sc += ms;
+    }
+    if (update_ms_sum) *update_ms_sum = su;
+    if (n_update) *n_update = (int)p->t_upd.size();
+    if (chainback_ms_sum) *chainback_ms_sum = sc;
+    if (n_chainback) *n_chainback = (int)p->t_cb.size();
+    for (auto &pr : p->t_upd) { p->ev_pool.push_back(pr.first); p->ev_pool.push_back(pr.second); }
+    for (auto &pr : p->t_cb) { p->ev_pool.push_back(pr.first); p->ev_pool.push_back(pr.second); }
+    p->t_upd.clear();
+    p->t_cb.clear();
+    return 0;
+}
+
+int vhip_get_pipeline_depth(const vhip_decoder *p) { return p ? p->depth : -1; }
+
+int vhip_set_pipeline_depth(vhip_decoder *p, int depth) {
+    if (!p) return fail("set_pipeline_depth: NULL handle");
+    if (use_device(p) != 0) return -1;
+    if (depth < 1 || depth > vhip_decoder::MAX_DEPTH) return fail("set_pipeline_depth: depth must be 1..3");
+    if (p->depth != 1 || p->pos != 0) return fail("set_pipeline_depth: only once, on a fresh handle");
+    if (depth == 1) return 0;
+    if (p->code == VHIP_KA9Q224) return fail("set_pipeline_depth: K=24 handles keep several frames in flight by themselves");
     HIP_TRY(hipStreamSynchronize(p->stream));
+    const size_t dec_bytes = (size_t)p->frames_padded * (size_t)p->cap_rows * p->row_bytes;
+    const size_t met_bytes = (size_t)p->nframes * p->N * sizeof(int16_t);
+    p->slots[0].d_dec = p->d_dec;
+    p->slots[0].d_metrics = p->d_metrics;
+    hipError_t e = hipEventCreateWithFlags(&p->ev_input, hipEventDisableTiming);
+    for (int i = 0; i < depth && e == hipSuccess; i++) {
+        vhip_decoder::Slot &sl = p->slots[i];
+        if (i > 0) {
+            e = hipMalloc(reinterpret_cast<void **>(&sl.d_dec), dec_bytes ? dec_bytes : 16);
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&sl.d_metrics), met_bytes);
+            if (e == hipSuccess) e = hipMemset(sl.d_dec, 0, dec_bytes ? dec_bytes : 16);
+            if (e == hipSuccess) e = vh::launch_init_metrics(sl.d_metrics, p->N, p->nframes, init_all_of(p->code), init_start_of(p->code), 0, p->stream);
+            if (e == hipSuccess) p->total_bytes += dec_bytes + met_bytes;
+        }
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    p->depth = depth;  // from here on vhip_delete releases the slots
+    p->cur_slot = 0;
+    if (e != hipSuccess) return fail("set_pipeline_depth: allocation", e);
+    return 0;
+}
+
+// Orders everything the handle has in flight on its internal streams before whatever the caller enqueues next on the
+// handle's stream (device-side wait; the host does not block).
+int vhip_join(vhip_decoder *p) {
+    if (!p) return fail("join: NULL handle");
+    if (use_device(p) != 0) return -1;
+    for (int i = 0; i < p->depth && p->depth > 1; i++) {
+        HIP_TRY(hipEventRecord(p->slots[i].done, p->slots[i].stream));
+        HIP_TRY(hipStreamWaitEvent(p->stream, p->slots[i].done, 0));
+    }
     return 0;
 }
 
@@ -424,10 +585,20 @@ size_t vhip_device_bytes(const vhip_decoder *p) { return p ? p->total_bytes : 0;
 
 // init_viterbi27_sse2 (viterbi27_sse2.cpp:42-54) for every frame of the handle
 int vhip_init(vhip_decoder *p, int starting_state) {
+    StatusScope status_scope(p);
     if (!p) return fail("init: NULL handle");  // viterbi224_sse2.cpp:36-37 returns -1 on NULL
     if (use_device(p) != 0) return -1;
     const unsigned start = (unsigned)starting_state & (p->N - 1);
     const int ia = init_all_of(p->code), is = init_start_of(p->code);
+    if (p->depth > 1) {
+        // a new decode begins: take the next buffer set and its stream (the previous decode's chainback may still be
+        // walking the other history)
+        p->slots[p->cur_slot].pos = p->pos;
+        p->cur_slot = (p->cur_slot + 1) % p->depth;
+        p->d_dec = p->slots[p->cur_slot].d_dec;
+        p->d_metrics = p->slots[p->cur_slot].d_metrics;
+        if (order_behind_caller(p) != 0) return -1;
+    }
     if (p->code == VHIP_KA9Q224) {
         // only the first half of each frame's ping-pong needs filling; mark it current
         for (int f = 0; f < p->nframes; f++) {
@@ -436,13 +607,14 @@ int vhip_init(vhip_decoder *p, int starting_state) {
         }
         HIP_TRY(vh::launch_k24_flags_reset(p->d_flags, p->stream));
     } else {
-        HIP_TRY(vh::launch_init_metrics(p->d_metrics, p->N, p->nframes, ia, is, start, p->stream));
+        HIP_TRY(vh::launch_init_metrics(p->d_metrics, p->N, p->nframes, ia, is, start, p->run_stream()));
     }
     p->pos = 0;
     return 0;
 }
 
 int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
+    StatusScope status_scope(p);
     if (!p) return fail("update: NULL handle");
     if (use_device(p) != 0) return -1;
     if (nbits <= 0) return 0;
@@ -453,6 +625,12 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
     }
     if (row0 + steps > p->cap_rows) return fail("update: more trellis steps than the handle was created for");
     const size_t sym_stride = (size_t)nbits * p->R;
+    if (order_behind_caller(p) != 0) return -1;
+    struct TimeScope {  // the closing event is recorded on every path out of the launches below
+        hipEvent_t e1;
+        hipStream_t st;
+        ~TimeScope() { timing_end(e1, st); }
+    } time_scope{timing_begin(p, p->t_upd, p->run_stream()), p->run_stream()};
     if (p->code == VHIP_KA9Q224) {
         if (p->variant == VHIP_VARIANT_HBM_FUSED && p->nframes > 1) {
             // A single K=24 decode leaves the chip under-occupied between its load/compute/store phases (two concurrent
@@ -493,7 +671,7 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
         a.nframes = p->nframes;
         a.dec = p->d_dec;
         a.metrics = p->d_metrics;
-        HIP_TRY(vh::launch_acs_k15(a, p->code == VHIP_SPIRAL615, p->stream));
+        HIP_TRY(vh::launch_acs_k15(a, p->code == VHIP_SPIRAL615, p->run_stream()));
     } else if (p->variant == VHIP_VARIANT_REGS) {
         vh::AcsRegsArgs a;
         a.syms = d_syms;
@@ -504,7 +682,7 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
         a.nframes = p->nframes;
         a.dec = p->d_dec;
         a.metrics = p->d_metrics;
-        HIP_TRY(vh::launch_acs_regs(p->code, p->regs_lb, a, p->stream));
+        HIP_TRY(vh::launch_acs_regs(p->code, p->regs_lb, a, p->run_stream()));
     } else {
         vh::AcsLdsArgs a;
         a.syms = d_syms;
@@ -516,16 +694,23 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
         a.dec = p->d_dec;
         a.metrics = p->d_metrics;
         for (int r = 0; r < 8; r++) a.poly[r] = p->poly[r];
-        HIP_TRY(vh::launch_acs_lds(p->code, a, p->stream));
+        HIP_TRY(vh::launch_acs_lds(p->code, a, p->run_stream()));
     }
     p->pos = row0 + steps;
     return 0;
 }
 
 int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbits, unsigned int endstate) {
+    StatusScope status_scope(p);
     if (!p) return fail("chainback: NULL handle");
     if (use_device(p) != 0) return -1;
     if (nbits == 0) return 0;
+    if (order_behind_caller(p) != 0) return -1;
+    struct TimeScope {
+        hipEvent_t e1;
+        hipStream_t st;
+        ~TimeScope() { timing_end(e1, st); }
+    } time_scope{timing_begin(p, p->t_cb, p->run_stream()), p->run_stream()};
     if (p->variant == VHIP_VARIANT_HBM_FUSED) {
         vh::ChainbackRowsArgs a;
         a.dec = p->d_dec;
@@ -555,8 +740,8 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
         a.K = p->K;
         a.k224 = 0;
         a.k15_sign_bytes = p->code == VHIP_KA9Q615;
-        if (getenv("VHIP_CHAINBACK_SIMPLE")) HIP_TRY(vh::launch_chainback_k15(a, p->stream));
-        else HIP_TRY(vh::launch_chainback_spec(a.k15_sign_bytes ? vh::CB_LAY_K15_SIGN_BYTES : vh::CB_LAY_K15, a, p->stream));
+        if (getenv("VHIP_CHAINBACK_SIMPLE")) HIP_TRY(vh::launch_chainback_k15(a, p->run_stream()));
+        else HIP_TRY(vh::launch_chainback_spec(a.k15_sign_bytes ? vh::CB_LAY_K15_SIGN_BYTES : vh::CB_LAY_K15, a, p->run_stream()));
         return 0;
     }
     if (p->variant == VHIP_VARIANT_REGS) {
@@ -571,7 +756,7 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
         a.nbits = nbits;
         a.endstate = endstate;
         a.K = p->K;
-        HIP_TRY(vh::launch_chainback_regs(a, p->stream));
+        HIP_TRY(vh::launch_chainback_regs(a, p->run_stream()));
         return 0;
     }
     vh::ChainbackRowsArgs a;
@@ -585,41 +770,45 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
     a.endstate = endstate;
     a.K = p->K;
     a.k224 = (p->code == VHIP_KA9Q224);
-    if (p->K >= 15 && !getenv("VHIP_CHAINBACK_SIMPLE")) HIP_TRY(vh::launch_chainback_spec(vh::CB_LAY_NATURAL, a, p->stream));
-    else HIP_TRY(vh::launch_chainback_rows(a, p->stream));
+    if (p->K >= 15 && !getenv("VHIP_CHAINBACK_SIMPLE")) HIP_TRY(vh::launch_chainback_spec(vh::CB_LAY_NATURAL, a, p->run_stream()));
+    else HIP_TRY(vh::launch_chainback_rows(a, p->run_stream()));
     return 0;
 }
 
 int vhip_update(vhip_decoder *p, const unsigned char *syms, int nbits) {
+    StatusScope status_scope(p);
     if (!p) return fail("update: NULL handle");
     if (use_device(p) != 0) return -1;
     if (nbits <= 0) return 0;
     const size_t bytes = (size_t)p->nframes * (size_t)nbits * p->R;
     if (ensure_stage(&p->d_syms_stage, &p->syms_stage_bytes, bytes, &p->total_bytes) != 0) return -1;
+    if (p->depth > 1 && sync_all(p) != 0) return -1;  // the staging buffer is shared between the decodes in flight
     HIP_TRY(hipMemcpyAsync(p->d_syms_stage, syms, bytes, hipMemcpyHostToDevice, p->stream));
     if (vhip_update_dev(p, p->d_syms_stage, nbits) != 0) return -1;
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipStreamSynchronize(p->run_stream()));
     return 0;
 }
 
 int vhip_chainback(vhip_decoder *p, unsigned char *data, unsigned int nbits, unsigned int endstate) {
+    StatusScope status_scope(p);
     if (!p) return fail("chainback: NULL handle");
     if (use_device(p) != 0) return -1;
     int ret = 0;
     if (p->code == VHIP_KA9Q615 && p->nframes == 1) {
         // chainback_viterbi615_sse2 returns old_metrics->s[endstate]            viterbi615_sse2.cpp:76,90
         int16_t m = 0;
-        HIP_TRY(hipMemcpyAsync(&m, p->d_metrics + (endstate % p->N), sizeof(m), hipMemcpyDeviceToHost, p->stream));
-        HIP_TRY(hipStreamSynchronize(p->stream));
+        HIP_TRY(hipMemcpyAsync(&m, p->d_metrics + (endstate % p->N), sizeof(m), hipMemcpyDeviceToHost, p->run_stream()));
+        HIP_TRY(hipStreamSynchronize(p->run_stream()));
         ret = m;
     }
     if (nbits == 0) return ret;
     const size_t stride = (nbits + 7) / 8;
     const size_t bytes = (size_t)p->nframes * stride;
     if (ensure_stage(&p->d_data_stage, &p->data_stage_bytes, bytes, &p->total_bytes) != 0) return -1;
+    if (p->depth > 1 && sync_all(p) != 0) return -1;
     if (vhip_chainback_dev(p, p->d_data_stage, nbits, endstate) != 0) return -1;
-    HIP_TRY(hipMemcpyAsync(data, p->d_data_stage, bytes, hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpyAsync(data, p->d_data_stage, bytes, hipMemcpyDeviceToHost, p->run_stream()));
+    HIP_TRY(hipStreamSynchronize(p->run_stream()));
     return ret;
 }
 
@@ -628,7 +817,7 @@ int vhip_read_decision_rows(vhip_decoder *p, int frame, int row0, int nrows, uns
     if (use_device(p) != 0) return -1;
     if (frame < 0 || frame >= p->nframes || row0 < 0 || nrows < 0 || row0 + nrows > p->cap_rows)
         return fail("read_decision_rows: out of range");
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (sync_all(p) != 0) return -1;
     if (p->variant == VHIP_VARIANT_HBM_FUSED) {
         // position bitmap of acs_k24f.hip -> natural bitmap
         const int NB = 23;
@@ -699,7 +888,7 @@ int vhip_read_metrics(vhip_decoder *p, int frame, int32_t *out) {
     if (!p) return fail("read_metrics: NULL handle");
     if (use_device(p) != 0) return -1;
     if (frame < 0 || frame >= p->nframes) return fail("read_metrics: out of range");
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (sync_all(p) != 0) return -1;
     std::vector<int16_t> tmp(p->N);
     const int16_t *src = (p->code == VHIP_KA9Q224)
                              ? p->d_metrics + ((size_t)frame * 2 + p->k24_cur[frame]) * p->N

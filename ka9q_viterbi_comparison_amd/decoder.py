@@ -20,7 +20,7 @@ def _is_torch(x):
 
 
 class HipViterbi:
-    def __init__(self, code, transmit_bits, nframes=1, poly=None, variant=VARIANT_AUTO, stream=None):
+    def __init__(self, code, transmit_bits, nframes=1, poly=None, variant=VARIANT_AUTO, stream=None, pipeline_depth=1):
         spec = CODES[code] if isinstance(code, str) else BY_ID[code]
         self.spec = spec
         self.K, self.R = spec.K, spec.R
@@ -36,6 +36,8 @@ class HipViterbi:
             _lib.check(self._lib.vhip_set_variant(self._h, variant), "vhip_set_variant")
         if stream is not None:
             self.set_stream(stream)
+        if pipeline_depth != 1:
+            _lib.check(self._lib.vhip_set_pipeline_depth(self._h, pipeline_depth), "vhip_set_pipeline_depth")
 
     # -- lifetime ----------------------------------------------------------------------------------
     def close(self):
@@ -62,6 +64,27 @@ class HipViterbi:
 
     def sync(self):
         _lib.check(self._lib.vhip_sync(self._h), "vhip_sync")
+
+    def join(self):
+        """Pipelined handles: order everything in flight before what the caller enqueues next on the handle's stream."""
+        _lib.check(self._lib.vhip_join(self._h), "vhip_join")
+
+    def enable_timing(self, on=True):
+        _lib.check(self._lib.vhip_enable_timing(self._h, int(on)), "vhip_enable_timing")
+
+    def read_timing(self):
+        """Waits for the handle to go idle; -> (update_ms_sum, n_update, chainback_ms_sum, n_chainback) since the last read."""
+        su, sc, nu, nc = C.c_double(0), C.c_double(0), C.c_int(0), C.c_int(0)
+        _lib.check(self._lib.vhip_read_timing(self._h, C.byref(su), C.byref(nu), C.byref(sc), C.byref(nc)), "vhip_read_timing")
+        return su.value, nu.value, sc.value, nc.value
+
+    @property
+    def pipeline_depth(self):
+        return self._lib.vhip_get_pipeline_depth(self._h)
+
+    @property
+    def status(self):
+        return self._lib.vhip_status(self._h)
 
     @property
     def variant(self):
@@ -103,10 +126,10 @@ class HipViterbi:
             return out, rc
         data = np.zeros((self.nframes, nbytes), dtype=np.uint8)  # caller pre-zeroes in the reference (main.cpp:262)
         rc = self._lib.vhip_chainback(self._h, data.ctypes.data_as(C.c_void_p), total_bits, endstate)
-        # ka9q615 with one frame legitimately returns a (usually negative) path metric (viterbi615_sse2.cpp:90);
-        # for every other code a negative value is an error
-        if rc < 0 and not (self.spec.name == "615" and self.nframes == 1):
-            _lib.check(rc, "vhip_chainback")
+        # ka9q615 with one frame legitimately returns a (usually negative) path metric (viterbi615_sse2.cpp:90), so the
+        # error status travels separately (vhip_status)
+        if self._lib.vhip_status(self._h) != 0:
+            raise _lib.VhipError(f"vhip_chainback failed: {_lib.last_error()}")
         return data, rc
 
     # -- introspection for parity tests --------------------------------------------------------------

@@ -50,3 +50,51 @@ def test_common_frames_helper_shapes():
         spec = spec_of(code)
         p, s = frames(code, 3, 2, 5, spec.ebn0_db)
         assert p.shape == (2, 5) and s.shape == (2, (40 + spec.K - 1) * spec.R)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["27", "47", "29", "49", "615", "224"])
+@pytest.mark.parametrize("mode", ["hard", "awgn"])
+def test_device_generator_equals_host_twin(name, mode):
+    """vhip_gen_frames_dev (csrc/framegen.hip) == vhip_gen_frames_host byte for byte: payload and symbols, hard and
+    AWGN, every harness polynomial set, frame0 != 0, a frame count that is not a multiple of the launch geometry.
+    bench.py and the full-size tests decode what the DEVICE generator produced, so this is what ties them to the host
+    frames the oracle is run on."""
+    import torch
+
+    from ka9q_viterbi_comparison_amd import gen_frames_dev
+
+    spec = C.CODES[name]
+    B = 9 if spec.K == 24 else 37
+    nframes, frame0, seed = 131, 1000003, 0x5EED
+    steps = B * 8 + spec.K - 1
+    amp_q16, nq = (C.HARD_AMP_Q16, 0) if mode == "hard" else (C.SOFT_AMP_Q16, noise_q12(spec.R, C.SOFT_AMP, spec.ebn0_db))
+    hp, hs = gen_frames_host(spec, seed, frame0, nframes, B, amp_q16, nq)
+    d_payload = torch.full((nframes * B,), 0xAA, dtype=torch.uint8, device="cuda")
+    d_syms = torch.full((nframes * steps * spec.R,), 0xAA, dtype=torch.uint8, device="cuda")
+    gen_frames_dev(spec, seed, frame0, nframes, B, amp_q16, nq, d_payload, d_syms, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_payload.cpu().numpy().reshape(nframes, B), hp)
+    assert np.array_equal(d_syms.cpu().numpy().reshape(nframes, steps * spec.R), hs)
+    if mode == "awgn":
+        assert len(np.unique(hs)) > 100  # really soft symbols, not a degenerate noise scale
+
+
+@pytest.mark.gpu
+def test_device_bit_error_count_equals_numpy_popcount():
+    """vhip_count_bit_errors_dev (the BER reduction of src/util.h:64-73) against numpy on ragged sizes."""
+    import torch
+
+    from ka9q_viterbi_comparison_amd import count_bit_errors_dev
+
+    rng = np.random.default_rng(5)
+    for n in (1, 3, 255, 4096, 1000003):
+        a = rng.integers(0, 256, n, dtype=np.uint8)
+        b = a.copy()
+        flip = rng.random(n) < 0.3
+        b[flip] ^= rng.integers(1, 256, int(flip.sum()), dtype=np.uint8)
+        want = int(np.unpackbits(a ^ b).sum())
+        got = count_bit_errors_dev(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), n, torch.cuda.current_stream().cuda_stream)
+        assert got == want, n
+    z = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    assert count_bit_errors_dev(z, z, 16) == 0

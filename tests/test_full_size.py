@@ -145,3 +145,66 @@ def test_pure_noise_cross_kernel_stress(name):
         out0 = results[0][0].reshape(frames, bits // 8)
         for f in (0, frames - 1):
             assert np.array_equal(out0[f], oracle_frame(spec, host[f], steps, bits))
+
+
+def test_config5_shard_size_k7_131072_frames():
+    """configs[4] per-GPU shard: 1M frames / 8 GPUs = 131072 frames of K=7 r=1/2 x 2048 bits on one handle -- the first
+    batch whose decision history (2.15 GB) has byte offsets beyond 2^31.  Round trip on every frame (noise-free: zero
+    bit errors), the L=1 and L=2 register kernels agree on every decoded byte of the AWGN batch (CRC), and frames sampled
+    from both ends and from beyond the 2^31-byte mark equal the CPU oracle exactly (sampled, not the whole batch)."""
+    frames, bits = 131072, 2048
+    spec, d_payload, d_syms, d_out = decode_batch("27", frames, bits, hard=True, seed=0x5EED)
+    assert count_bit_errors_dev(d_out, d_payload, frames * bits // 8) == 0
+    sums = []
+    for variant in (VARIANT_REGS | (2 << 8), VARIANT_REGS | (1 << 8)):
+        spec, d_payload, d_syms, d_out = decode_batch("27", frames, bits, hard=False, variant=variant)
+        sums.append(zlib.crc32(d_out.cpu().numpy().tobytes()))
+    assert sums[0] == sums[1]
+    steps = bits + spec.K - 1
+    out = d_out.cpu().numpy().reshape(frames, bits // 8)
+    for f in (0, 65535, 65536, 130689, 130690, 130700, 131071):
+        s = d_syms[f * steps * spec.R:(f + 1) * steps * spec.R].cpu().numpy()
+        assert np.array_equal(out[f], oracle_frame(spec, s, steps, bits)), f
+    errs = count_bit_errors_dev(d_out, d_payload, frames * bits // 8)
+    assert 0 < errs < frames * bits * 1e-3
+
+
+@pytest.mark.parametrize("name,frames,chunk,bits", [("615", 256, 64, 256), ("27", 4096, 1024, 512), ("49", 512, 128, 256)])
+def test_bench_chunked_shard(name, frames, chunk, bits):
+    """bench.py's chunked path (nchunks > 1: batches whose decision history does not fit are decoded in chunks of frames
+    that reuse one double-buffered handle): the very HipShard object bench.py drives.  Two passes agree with each other
+    byte for byte, the decoded batch equals an unchunked single-handle decode, sampled frames equal the CPU oracle, and
+    the live event timing saw every launch."""
+    import argparse
+
+    import bench
+
+    spec = C.CODES[name]
+    args = argparse.Namespace(code=name, payload_bits=bits, ebn0=None, hard=False, variant=0, chunk_frames=chunk,
+                              hbm_budget_gb=200.0, pipeline_depth=2)
+    dev = torch.device("cuda", 0)
+    frame0 = 777
+    shard = bench.HipShard(args, spec, dev, frame0, frames)
+    assert shard.nchunks == frames // chunk and shard.dec.pipeline_depth == 2
+    shard.drain()
+    for i in range(3):
+        shard.one_pass(i)
+    shard.drain()
+    st = shard.stats()  # asserts that the two output buffers (alternate passes) are identical
+    assert st["timed_update_launches"] == 3 * shard.nchunks and st["update_ms"] > 0 and st["chainback_ms"] > 0
+    steps = bits + spec.K - 1
+    got = shard.d_out[0].cpu().numpy().reshape(frames, bits // 8)
+    # unchunked, unpipelined decode of the same symbols
+    one = HipViterbi(name, steps, nframes=frames, stream=torch.cuda.current_stream().cuda_stream)
+    d_out = torch.zeros(frames * (bits // 8), dtype=torch.uint8, device=dev)
+    one.reset()
+    one.update(shard.d_syms, nbits=steps)
+    one.chainback(bits, out=d_out)
+    torch.cuda.synchronize()
+    one.close()
+    assert np.array_equal(got, d_out.cpu().numpy().reshape(frames, bits // 8))
+    syms = shard.d_syms.cpu().numpy().reshape(frames, steps * spec.R)
+    for f in (0, chunk - 1, chunk, frames - 1):
+        assert np.array_equal(got[f], oracle_frame(spec, syms[f], steps, bits)), f
+    assert st["bit_errors"] == count_bit_errors_dev(d_out, shard.d_payload, frames * bits // 8)
+    shard.close()

@@ -134,21 +134,28 @@ def test_spiral_restart_and_odd_step(code, variant):
 def test_endstate_start_state_and_ragged_bits(code, variant):
     """Non-zero starting state, non-zero end state, bit counts that are not multiples of 8."""
     spec = spec_of(code)
-    if spec.K == 24:
-        pytest.skip("covered by test_k24_chainback_variants")
-    B = 12
+    # K=24 (init_viterbi224_sse2 / chainback_viterbi224_sse2, viterbi224_sse2.cpp:32-47,79-121): a short frame keeps the
+    # oracle's 8M-state scalar walk to seconds; the oracle is pinned on these arguments by
+    # test_oracle_vs_reference.py::test_k24_start_state_end_state_ragged_bits
+    B = 4 if spec.K == 24 else 12
+    nframes = 2 if spec.K == 24 else 3
     steps = B * 8 + spec.K - 1
-    _, syms = frames(code, 21, 3, B, spec.ebn0_db)
+    _, syms = frames(code, 21, nframes, B, spec.ebn0_db)
     N = 1 << (spec.K - 1)
-    for start, end, nbits in [(5, 0, B * 8), (N - 1, 3, B * 8 - 3), (0, N + 9, 13)]:
-        dec = HipViterbi(spec.name, steps, nframes=3, variant=variant)
+    cases = [(5, 0, B * 8), (N - 1, 3, B * 8 - 3), (0, N + 9, 13)]
+    if spec.K == 24:
+        cases = [(5, 0, B * 8), (N - 1, 3, steps - 3), (0x2AAAAA, N + 0x155555, steps)]
+    for start, end, nbits in cases:
+        dec = HipViterbi(spec.name, steps, nframes=nframes, variant=variant)
         dec.reset(start)
         dec.update(syms)
         data, _ = dec.chainback(nbits, endstate=end)
-        for f in range(3):
+        for f in range(nframes):
             ref = oracle_decode(code, syms[f], steps, nbits, endstate=end, start=start)
             assert np.array_equal(data[f], ref["data"])
             assert np.array_equal(dec.metrics(f), ref["metrics"])
+            if spec.K == 24:
+                assert np.array_equal(dec.decision_rows(f, 0, steps), ref["rows"])
         dec.close()
 
 
@@ -224,16 +231,121 @@ def test_k24_renormalisation_and_incremental(variant):
     dec.close()
 
 
+def test_k24_many_frames_per_handle():
+    """Seven K=24 frames on one handle: with VARIANT_HBM_FUSED each of the three in-flight decode slots takes several
+    frames in turn, every one through a renormalisation (viterbi224_sse2.cpp:226-246) and its speculative replay.
+    Frames 0 and 6 are checked against the oracle (rows sampled, metrics, bytes); all seven against the per-step
+    kernel family (VARIANT_HBM, oracle-checked above) on metrics and decoded bytes."""
+    code = C.KA9Q224
+    spec = spec_of(code)
+    B, nframes = 56, 7
+    steps = B * 8 + spec.K - 1
+    payload, syms = frames(code, 31, nframes, B, spec.ebn0_db)
+    out = {}
+    for variant in (VARIANT_HBM_FUSED, VARIANT_HBM):
+        dec = HipViterbi("224", steps, nframes=nframes, variant=variant)
+        dec.reset()
+        dec.update(syms)
+        data, _ = dec.chainback(steps)
+        out[variant] = (data.copy(), np.stack([dec.metrics(f) for f in range(nframes)]))
+        if variant == VARIANT_HBM_FUSED:
+            for f in (0, nframes - 1):
+                ref = oracle_decode(code, syms[f], steps, steps)
+                assert ref["renorms"] >= 1
+                assert np.array_equal(out[variant][1][f], ref["metrics"])
+                assert np.array_equal(data[f], ref["data"])
+                for r in (0, 22, 23, 200, steps - 1):
+                    assert np.array_equal(dec.decision_rows(f, r, 1), ref["rows"][r:r + 1]), f"frame {f} row {r}"
+        dec.close()
+    assert np.array_equal(out[VARIANT_HBM_FUSED][0], out[VARIANT_HBM][0])
+    assert np.array_equal(out[VARIANT_HBM_FUSED][1], out[VARIANT_HBM][1])
+    for f in range(nframes):
+        assert bit_errors(out[VARIANT_HBM_FUSED][0][f][:B], payload[f]) == 0
+
+
+@pytest.mark.parametrize("name,depth,nframes", [("27", 2, 300), ("27", 3, 70), ("47", 2, 130), ("29", 2, 70), ("615", 2, 3), ("spiral615", 2, 2)])
+def test_pipelined_handle_matches_oracle(name, depth, nframes):
+    """vhip_set_pipeline_depth: consecutive decodes on one handle rotate through `depth` decision-history buffers and
+    internal streams.  Five decodes of five DIFFERENT symbol batches are issued back to back with no host sync in
+    between (device-pointer API), each into its own output buffer; after vhip_join every output equals the oracle's for
+    ITS batch (sampled frames) and a strictly serial handle's (all frames), and the live timing saw every launch."""
+    import torch
+
+    spec = C.CODES[name]
+    code = spec.code
+    B = 20 if spec.K < 15 else 12
+    steps = B * 8 + spec.K - 1
+    steps -= 0 if spec_is_incremental(code) else steps % 2
+    stream = torch.cuda.current_stream().cuda_stream
+    dec = HipViterbi(name, steps, nframes=nframes, stream=stream, pipeline_depth=depth)
+    assert dec.pipeline_depth == depth
+    dec.enable_timing(True)
+    ser = HipViterbi(name, steps, nframes=nframes, stream=stream)
+    batches, outs, refs = [], [], []
+    for k in range(5):
+        _, syms = frames(code, 900 + k, nframes, B, spec.ebn0_db)
+        syms = np.ascontiguousarray(syms[:, :steps * spec.R])
+        batches.append((syms, torch.from_numpy(syms).cuda()))
+        outs.append(torch.zeros(nframes * B, dtype=torch.uint8, device="cuda"))
+        refs.append(torch.zeros(nframes * B, dtype=torch.uint8, device="cuda"))
+    torch.cuda.synchronize()
+    for k in range(5):
+        dec.reset()
+        dec.update(batches[k][1], nbits=steps)
+        dec.chainback(B * 8, out=outs[k])
+    dec.join()
+    for k in range(5):
+        ser.reset()
+        ser.update(batches[k][1], nbits=steps)
+        ser.chainback(B * 8, out=refs[k])
+    torch.cuda.synchronize()
+    su, nu, sc, nc = dec.read_timing()
+    assert nu == 5 and nc == 5 and su > 0 and sc > 0
+    for k in range(5):
+        got = outs[k].cpu().numpy().reshape(nframes, B)
+        assert np.array_equal(got, refs[k].cpu().numpy().reshape(nframes, B)), f"decode {k} differs from the serial handle"
+        for f in sorted({0, nframes // 2, nframes - 1}):
+            assert np.array_equal(got[f], oracle_decode(code, batches[k][0][f], steps, B * 8)["data"]), (k, f)
+    # introspection reads the CURRENT buffer set (decode 4)
+    ref = oracle_decode(code, batches[4][0][0], steps, B * 8)
+    assert np.array_equal(dec.decision_rows(0, 0, ref["rows"].shape[0]), ref["rows"])
+    assert np.array_equal(dec.metrics(0), ref["metrics"])
+    # host-pointer calls still work on a pipelined handle (they drain it first)
+    dec.reset()
+    dec.update(batches[1][0], nbits=steps)
+    data, _ = dec.chainback(B * 8)
+    assert np.array_equal(data, refs[1].cpu().numpy().reshape(nframes, B))
+    dec.close()
+    ser.close()
+
+
+def test_pipeline_depth_argument_checks():
+    from ka9q_viterbi_comparison_amd._lib import VhipError
+
+    with pytest.raises(VhipError):
+        HipViterbi("224", 40, pipeline_depth=2)  # K=24 keeps several frames in flight by itself
+    with pytest.raises(VhipError):
+        HipViterbi("27", 40, pipeline_depth=4)
+    d = HipViterbi("27", 40, nframes=2, pipeline_depth=2)
+    assert d.status == 0
+    with pytest.raises(VhipError):
+        d.update(np.zeros((2, 400 * 2), np.uint8), nbits=400)  # more steps than the handle was created for
+    assert d.status == -1
+    d.reset()
+    assert d.status == 0
+    d.close()
+
+
 def spec_is_incremental(code):
     return code in (C.KA9Q27, C.KA9Q29, C.KA9Q615, C.KA9Q224)
 
 
-@pytest.mark.parametrize("code,variant", [c for c in CASES if c[0] != C.KA9Q224])
+@pytest.mark.parametrize("code,variant", CASES)
 def test_adversarial_symbols(code, variant):
     """Saturation / wrap-around corner cases: all-0, all-255, erasure-like mid-scale symbols, alternating extremes,
     ramps and uniform noise -- one pattern per frame of a batch, every row / metric / byte against the oracle."""
     spec = spec_of(code)
-    B = 16 if spec.K < 15 else 10
+    B = 16 if spec.K < 15 else (10 if spec.K == 15 else 3)
     steps = B * 8 + spec.K - 1
     if not spec_is_incremental(code):
         steps -= steps % 2
@@ -245,6 +357,8 @@ def test_adversarial_symbols(code, variant):
         rng.integers(0, 256, n, dtype=np.uint8), rng.choice(np.array([0, 255], np.uint8), n),
         rng.choice(np.array([0, 127, 128, 255], np.uint8), n),
     ])
+    if spec.K == 24:
+        pats = pats[[0, 1, 2, 4, 6]]  # each oracle frame is an 8M-state scalar walk
     dec = HipViterbi(spec.name, steps, nframes=len(pats), variant=variant)
     dec.reset()
     dec.update(pats, nbits=steps)

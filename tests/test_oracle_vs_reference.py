@@ -156,6 +156,48 @@ def test_start_state_end_state_ragged_bits(code):
         r.close()
 
 
+def test_k24_start_state_end_state_ragged_bits():
+    """init_viterbi224_sse2(p, starting_state != 0) (viterbi224_sse2.cpp:32-47) and chainback_viterbi224_sse2 with
+    endstate != 0 / ragged bit counts (:79-121, endstate masked at :90): a short frame keeps the 8M-state scalar
+    walk to seconds.  Rows, metrics, decoded bytes and return code against the genuine reference object."""
+    code = C.KA9Q224
+    spec = spec_of(code)
+    B = 5
+    steps = B * 8 + spec.K - 1
+    N = 1 << (spec.K - 1)
+    _, syms = frames(code, 8, 1, B, spec.ebn0_db)
+    for start, end, nbits in [(5, 0, B * 8), (N - 1, 3, steps - 3), (N + 2, N + 9, 13), (0x2AAAAA, 0x555555, steps)]:
+        o, r = both(code, steps)
+        assert o.init(start) == r.init(start)
+        o.update(syms[0], steps)
+        r.update(syms[0], steps)
+        compare(o, r, steps, nbits, end)
+        # a second chainback on the same history with another end state (the walk does not modify it)
+        do, _ = o.chainback(nbits, end ^ 0x40001)
+        dr, _ = r.chainback(nbits, end ^ 0x40001)
+        assert np.array_equal(do, dr)
+        o.close()
+        r.close()
+
+
+def test_k24_adversarial_symbols():
+    """Saturating adds of the K=24 family at their corners (all-0 / all-255 / mid-scale / alternating symbols)."""
+    code = C.KA9Q224
+    spec = spec_of(code)
+    B = 3
+    steps = B * 8 + spec.K - 1
+    n = steps * spec.R
+    rng = np.random.default_rng(7)
+    for s in [np.zeros(n, np.uint8), np.full(n, 255, np.uint8), np.full(n, 128, np.uint8),
+              np.tile(np.array([0, 255], np.uint8), n)[:n], rng.integers(0, 256, n, dtype=np.uint8)]:
+        o, r = both(code, steps)
+        o.update(s, steps)
+        r.update(s, steps)
+        compare(o, r, steps, steps)
+        o.close()
+        r.close()
+
+
 def test_ka9q615_lp64_chainback_defect_is_documented():
     """the shipped K=15 chainback indexes 64-bit words on LP64 and decodes wrongly even without
     noise; update (rows, metrics) is unaffected.  The oracle follows the 32-bit-word semantics."""

@@ -1,5 +1,7 @@
 """N>1 path on CPU: two gloo ranks take their frame shards, decode them (with the CPU oracle standing in for the
-device, as tests may), and the union equals the single-process result; timing reduces with MAX, counters with SUM."""
+device, as tests may), and the union equals the single-process result; timing reduces with MAX, counters with SUM.
+test_bench_job_loop_two_ranks drives the very function bench.py runs (sharding.run_sharded_job: shard ranges, warm-up,
+barrier, timed passes, MAX / SUM reductions, the core of the JSON line) with a CPU shard in place of the HIP one."""
 import os
 import socket
 import sys
@@ -89,3 +91,92 @@ def test_two_rank_shards_equal_single_process(tmp_path):
         ref[i], _ = o.chainback(B * 8)
         o.close()
     assert np.array_equal(np.concatenate(outs), ref)
+
+
+class _CpuShard:
+    """What bench.py's HipShard is to run_sharded_job, with the CPU oracle as the decoder (test stand-in only)."""
+
+    def __init__(self, frame_lo, nframes, rank, out_dir):
+        from common import frames, spec_of
+        from ka9q_viterbi_comparison_amd import codes as C
+
+        self.code, self.spec = C.KA9Q27, spec_of(C.KA9Q27)
+        self.B = 8
+        self.steps = self.B * 8 + self.spec.K - 1
+        self.frame_lo, self.nframes, self.rank, self.out_dir = frame_lo, nframes, rank, out_dir
+        self.payload, self.syms = frames(self.code, 0x5EED, nframes, self.B, None, frame0=frame_lo)  # hard symbols: error free
+        self.out = np.zeros((nframes, self.B), np.uint8)
+        self.passes, self.drains = 0, 0
+
+    def one_pass(self, i):
+        import time
+
+        from oracle_lib import OracleDecoder
+
+        for f in range(self.nframes):
+            o = OracleDecoder(self.code, self.spec.poly, self.steps)
+            o.update(self.syms[f], self.steps)
+            self.out[f], _ = o.chainback(self.B * 8)
+            o.close()
+        if self.rank == 1:
+            time.sleep(0.05)  # the slow rank sets the job's elapsed time
+        self.passes += 1
+
+    def drain(self):
+        self.drains += 1
+
+    def stats(self):
+        from common import bit_errors
+
+        np.save(os.path.join(self.out_dir, f"job_out{self.rank}.npy"), self.out)
+        return {"units_per_pass": self.nframes * self.steps * self.spec.R, "bit_errors": bit_errors(self.out, self.payload),
+                "passes": self.passes, "drains": self.drains, "frame_lo": self.frame_lo}
+
+
+def _job_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import json
+    import time
+
+    import torch.distributed as dist
+
+    from ka9q_viterbi_comparison_amd.sharding import run_sharded_job
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t0 = time.perf_counter()
+    core = run_sharded_job(lambda lo, n: _CpuShard(lo, n, rank, out_dir), frames_per_rank=5, steps=3, warmup=1, rank=rank, world=world)
+    wall = time.perf_counter() - t0
+    if rank == 0:
+        core["wall_s"] = wall
+        json.dump(core, open(os.path.join(out_dir, "core.json"), "w"))
+    else:
+        assert core is None
+    dist.destroy_process_group()
+
+
+def test_bench_job_loop_two_ranks(tmp_path):
+    import json
+
+    from common import frames, spec_of
+    from ka9q_viterbi_comparison_amd import codes as C
+
+    world = 2
+    mp.spawn(_job_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    core = json.load(open(tmp_path / "core.json"))
+    spec = spec_of(C.KA9Q27)
+    steps = 8 * 8 + spec.K - 1
+    assert core["n_gpus"] == 2 and core["steps"] == 3 and core["warmup"] == 1 and core["scaling"] == "weak"
+    assert core["units_per_pass_all_ranks"] == 2 * 5 * steps * spec.R  # SUM over ranks: whole-job units
+    assert core["bit_errors"] == 0
+    assert core["stats"]["passes"] == 4 and core["stats"]["drains"] == 2 and core["stats"]["frame_lo"] == 0
+    # elapsed is the MAX over ranks (rank 1 sleeps 50 ms per pass) and value = units * steps / elapsed
+    assert core["elapsed_s"] >= 3 * 0.05 and core["elapsed_s"] <= core["wall_s"]
+    assert abs(core["value"] - core["units_per_pass_all_ranks"] * 3 / core["elapsed_s"]) < 1e-6 * core["value"]
+    assert abs(core["ms_per_step"] - core["elapsed_s"] / 3 * 1e3) < 1e-9
+    # weak scaling: globally unique frame ids -> rank 1 decoded frames 5..9 of the same generator
+    payload, _ = frames(C.KA9Q27, 0x5EED, 10, 8, None)
+    assert np.array_equal(np.load(tmp_path / "job_out0.npy"), payload[:5])
+    assert np.array_equal(np.load(tmp_path / "job_out1.npy"), payload[5:])

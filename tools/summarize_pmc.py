@@ -11,6 +11,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 
 def mean_counter(path, kernel_sub, counter):
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
@@ -22,8 +25,12 @@ def main():
     code, fetch_csv, write_csv, ksub = sys.argv[1:5]
     f, nf = mean_counter(fetch_csv, ksub, "FETCH_SIZE")
     w, nw = mean_counter(write_csv, ksub, "WRITE_SIZE")
+    from kernel_hash import kernel_family, kernel_source_hash
+    from ka9q_viterbi_comparison_amd.codes import CODES
+
     out = {
         "kernel": ksub,
+        "kernel_source_sha256": kernel_source_hash(kernel_family(CODES[code].K)),
         "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w, "launches_averaged": [nf, nw],
         "fetch_correction": 2.0,
         "hbm_bytes_per_launch": int((2.0 * f + w) * 1024),

@@ -9,6 +9,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 
 def main():
     code, path, ksub, ms = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4])
@@ -19,7 +22,11 @@ def main():
     mean = {k: sum(v) / len(v) for k, v in vals.items()}
     valu = mean.get("SQ_INSTS_VALU", 0.0)
     peak = 1024 / 1.8e-9  # wave64 VOP3P instructions per second, whole chip (measured issue interval)
+    from kernel_hash import kernel_family, kernel_source_hash
+    from ka9q_viterbi_comparison_amd.codes import CODES
+
     out = {"kernel": ksub, "counters_mean": mean, "kernel_ms": ms,
+           "kernel_source_sha256": kernel_source_hash(kernel_family(CODES[code].K)),
            "valu_wave_instr_per_launch": valu,
            "achieved_ginstr_per_s": valu / (ms * 1e-3) / 1e9,
            "issue_ceiling_ginstr_per_s": peak / 1e9,
