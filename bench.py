@@ -190,9 +190,26 @@ class HipShard:
             errs = [count_bit_errors_dev(o, self.d_payload, self.frames * self.payload_bytes, self.stream.cuda_stream) for o in self.d_out]
             assert len(set(errs)) == 1 and all(torch.equal(self.d_out[0], o) for o in self.d_out), "passes disagree"
             nerr = errs[0]
+        # After the timed region: the same kernels one at a time (nothing else on the device), for the per-kernel roofline --
+        # in the timed region the update of step i+1 shares the chip with the chainback of step i.
+        alone_u = alone_c = 0.0
+        nalone = 3
+        sc_, oc_ = self.chunk * self.nsteps * self.spec.R, self.chunk * self.payload_bytes
+        for _ in range(nalone):
+            for c in range(self.nchunks):
+                self.dec.reset()
+                self.dec.sync()
+                self.dec.update(self.d_syms[c * sc_:(c + 1) * sc_], nbits=self.nsteps)
+                self.dec.sync()
+                self.dec.chainback(self.cb_bits, out=self.d_out[0][c * oc_:(c + 1) * oc_])
+                self.dec.sync()
+        au, _, ac, _ = self.dec.read_timing()
+        alone_u, alone_c = au / nalone, ac / nalone
         return {
             "units_per_pass": self.frames * self.nsteps * self.spec.R,
             "bit_errors": nerr,
+            "update_ms_alone": alone_u,
+            "chainback_ms_alone": alone_c,
             "update_ms": su / passes,          # per pass (all chunks), kernels only, on the stream they ran on
             "chainback_ms": sc / passes,
             "timed_update_launches": nu,
@@ -283,7 +300,7 @@ def main():
         variant = st["variant"]
         family = kernel_family(spec.K)
         abytes = algorithmic_bytes_per_frame_step(spec) * frames * nsteps  # per pass of one rank
-        mbytes = moved_bytes_per_frame_step(spec, variant, getattr(shard.dec, "k24_passes_per_period", None)) * frames * nsteps
+        mbytes = moved_bytes_per_frame_step(spec, variant, {4: 5, 5: 2}.get(variant)) * frames * nsteps
         achieved = mbytes / (upd_ms * 1e-3) / 1e9
         tv, tsrc = replayed_counter("traffic", args.code, family)
         vv, vsrc = replayed_counter("valu", args.code, family)
@@ -325,7 +342,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "acs_update", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": (tv or {}).get("hbm_bytes_per_launch"), "traffic_source": tsrc,
-                         "bytes_per_launch": int(mbytes), "algorithmic_bytes_per_launch": int(abytes)},
+                         "bytes_per_launch": int(mbytes), "algorithmic_bytes_per_launch": int(abytes),
+                         # the same kernel with nothing else on the device (3 passes after the timed region)
+                         "alone": {"update_ms": round(st["update_ms_alone"], 4), "achieved": round(mbytes / (st["update_ms_alone"] * 1e-3) / 1e9, 2),
+                                   "frac": round(mbytes / (st["update_ms_alone"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                   "chainback_ms": round(st["chainback_ms_alone"], 4)}},
             # the binding limit of the K<=15 ACS kernels: packed-integer VALU issue, not HBM
             "valu_issue": valu,
         }

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../include/hip_interface.h"
@@ -33,6 +34,7 @@ struct Args {
     unsigned long long seed = 0x5EED;
     int payload_bytes = 0;  // 0 = the reference's size for the code
     int gpus = 1;           // frame-range shards, one per device
+    bool host_api = false;  // the reference's own methodology: one frame per handle, host pointers, the five blocking functions
 };
 
 struct CodeBlock {
@@ -55,7 +57,9 @@ const CodeBlock BLOCKS[] = {
 void usage(const char *argv0) {
     fprintf(stderr,
             "usage: %s [-t seconds] [-n samples] [-o file.json] [--frames N] [--codes 27,47,...] [--ebn0 dB | --hard]\n"
-            "          [--payload-bytes B] [--seed S] [--gpus N]\n",
+            "          [--payload-bytes B] [--seed S] [--gpus N] [--host-api]\n"
+            "  --host-api: the reference's methodology (src/main.cpp:257-280) -- ONE frame per handle, host buffers, the five\n"
+            "              blocking reference-shaped functions (create_viterbi27_hip ...): PCIe copies and launch latency included\n",
             argv0);
 }
 
@@ -74,6 +78,7 @@ bool parse(int argc, char **argv, Args &a) {
         else if (k == "--seed") { if (!(v = val())) return false; a.seed = strtoull(v, nullptr, 0); }
         else if (k == "--payload-bytes") { if (!(v = val())) return false; a.payload_bytes = atoi(v); }
         else if (k == "--gpus") { if (!(v = val())) return false; a.gpus = atoi(v); }
+        else if (k == "--host-api") a.host_api = true;
         else if (k == "-h" || k == "--help") return false;
         else { fprintf(stderr, "unknown argument %s\n", k.c_str()); return false; }
     }
@@ -126,6 +131,59 @@ int main(int argc, char **argv) {
         const int bytes = args.payload_bytes > 0 ? args.payload_bytes : cb.ref_payload_bytes;
         const size_t decode_bits = (size_t)bytes * 8, transmit_bits = decode_bits + cb.K - 1, symbols = transmit_bits * cb.R;
         fprintf(stderr, "[test_run]\nK=%d, R=%d\ntotal_input_bytes = %d, frames = %d\n", cb.K, cb.R, bytes, frames);
+        if (args.host_api) {
+            // What a maintainer gets after INTEGRATION.md §2a: test_third_party's loop (src/main.cpp:257-280) over the
+            // reference-shaped entry points -- one frame, host pointers, every call blocking (H2D / D2H copies inside).
+            frames = 1;
+            std::vector<unsigned char> payload((size_t)bytes), syms(symbols), out((size_t)(transmit_bits + 7) / 8);
+            const int amp = args.hard ? (int)(127.5 * 65536) : 64 * 65536;
+            const int nqh = args.hard ? 0 : vhip_noise_q12_from_ebn0(cb.R, 64.0, args.ebn0 > 1e8 ? cb.default_ebn0 : args.ebn0);
+            if (vhip_gen_frames_host(cb.K, cb.R, cb.poly, args.seed, 0, 1, bytes, amp, nqh, payload.data(), syms.data()) != 0) return 2;
+            vhip_decoder *dec = vhip_create(cb.code, cb.poly, (int)transmit_bits, 1);
+            if (!dec) { fprintf(stderr, "%s\n", vhip_last_error()); return 2; }
+            std::vector<uint64_t> init_ns, update_ns, chainback_ns;
+            const auto t_total = clk::now();
+            for (size_t i = 0;; i++) {
+                const float elapsed = (float)ns_since(t_total) * 1e-9f;
+                if (elapsed > args.sampling_time && i > args.minimum_samples) break;
+                memset(out.data(), 0, out.size());  // main.cpp:262
+                auto t = clk::now();
+                vhip_init(dec, 0);
+                vhip_sync(dec);
+                init_ns.push_back(ns_since(t));
+                t = clk::now();
+                if (vhip_update(dec, syms.data(), (int)transmit_bits) != 0) { fprintf(stderr, "%s\n", vhip_last_error()); return 2; }
+                update_ns.push_back(ns_since(t));
+                t = clk::now();
+                (void)vhip_chainback(dec, out.data(), (unsigned)decode_bits, 0);
+                if (vhip_status(dec) != 0) { fprintf(stderr, "%s\n", vhip_last_error()); return 2; }
+                chainback_ns.push_back(ns_since(t));
+            }
+            if (cb.K == 24) (void)vhip_chainback(dec, out.data(), (unsigned)transmit_bits, 0);  // BER from the nbits+K-1 call
+            long long errors = 0;
+            for (int b = 0; b < bytes; b++) errors += __builtin_popcount((unsigned)(out[(size_t)b] ^ payload[(size_t)b]));
+            vhip_delete(dec);
+            double upd_mean = 0;
+            for (uint64_t v : update_ns) upd_mean += (double)v;
+            upd_mean /= (double)update_ns.size();
+            fprintf(fp, "%s{\n", first ? "" : ",\n");
+            first = false;
+            fprintf(fp, "  \"name\": \"hip_host_1frame\",\n  \"K\": %d,\n  \"R\": %d,\n  \"poly\": [", cb.K, cb.R);
+            for (int r = 0; r < cb.R; r++) fprintf(fp, "%s%d", r ? "," : "", cb.poly[r]);
+            fprintf(fp, "],\n  \"frames\": 1,\n  \"gpus\": 1,\n  \"frames_per_gpu\": 1,\n");
+            fprintf(fp, "  \"total_input_bytes\": %d,\n  \"total_transmit_bits\": %zu,\n  \"total_output_symbols\": %zu,\n", bytes, transmit_bits, symbols);
+            fprintf(fp, "  \"sampling_time\": %f,\n  \"minimum_samples\": %zu,\n  \"total_samples\": %zu,\n", args.sampling_time, args.minimum_samples, update_ns.size());
+            fprintf(fp, "  \"init_ns\": ");
+            print_u64_array(fp, init_ns);
+            fprintf(fp, ",\n  \"update_ns\": ");
+            print_u64_array(fp, update_ns);
+            fprintf(fp, ",\n  \"chainback_ns\": ");
+            print_u64_array(fp, chainback_ns);
+            fprintf(fp, ",\n  \"total_bits\": %zu,\n  \"total_bit_errors\": %lld,\n  \"bit_error_rate\": %f\n}", decode_bits, errors, (double)errors / (double)decode_bits);
+            fprintf(stderr, "o hip_host_1frame (%.6f)  update %.3f Msym/s (%.1f us per call)\n", (double)errors / (double)decode_bits,
+                    (double)symbols / (upd_mean * 1e-9) / 1e6, upd_mean * 1e-3);
+            continue;
+        }
         // One shard of `frames` frames per GPU (frames are independent -> frame-range sharding, no
         // collective).  All shards are driven from this thread: every call is asynchronous on its handle's stream, so
         // a phase is issued to all devices and then awaited; the phase time is first issue -> last completion.
@@ -170,8 +228,20 @@ int main(int argc, char **argv) {
             sync_all();
             init_ns.push_back(ns_since(t));
             t = clk::now();
-            for (Shard &sh : shards)
-                if (vhip_update_dev(sh.dec, sh.d_syms, (int)transmit_bits) != 0) { fprintf(stderr, "%s\n", vhip_last_error()); return 2; }
+            if (cb.K == 24 && args.gpus > 1) {
+                // the K=24 update blocks its caller (the host steers the speculative renormalisation): one thread per GPU,
+                // so that the shards run side by side and update_ns is the slowest shard, not the sum
+                std::vector<std::thread> th;
+                std::vector<int> rcs((size_t)args.gpus, 0);
+                for (int d = 0; d < args.gpus; d++)
+                    th.emplace_back([&, d]() { rcs[(size_t)d] = vhip_update_dev(shards[(size_t)d].dec, shards[(size_t)d].d_syms, (int)transmit_bits); });
+                for (auto &x : th) x.join();
+                for (int rc : rcs)
+                    if (rc != 0) { fprintf(stderr, "K=24 shard update failed\n"); return 2; }
+            } else {
+                for (Shard &sh : shards)
+                    if (vhip_update_dev(sh.dec, sh.d_syms, (int)transmit_bits) != 0) { fprintf(stderr, "%s\n", vhip_last_error()); return 2; }
+            }
             sync_all();
             update_ns.push_back(ns_since(t));
             t = clk::now();
@@ -201,7 +271,12 @@ int main(int argc, char **argv) {
         const int frames_per_gpu = frames;
         frames *= args.gpus;  // whole-job sizes below
         const size_t total_bits = (size_t)frames * decode_bits;
-        const double hbm_bytes = cb.K == 24 ? 34603010.0 * transmit_bits * frames
+        // bytes the ACS kernels move per update: K <= 15 the algorithmic R + N/8 per frame-step; K=24 by
+        // variant -- per-step kernel 34 603 010 B per step, multi-step passes (passes x 32 MiB + 23 x (1 MiB + 2)) per 23 steps
+        const int k24_variant = cb.K == 24 ? vhip_get_variant(shards[0].dec) : 0;
+        const double k24_step = k24_variant == VHIP_VARIANT_HBM_TILED ? (2 * 33554432.0 + 23 * 1048578.0) / 23.0
+                              : k24_variant == VHIP_VARIANT_HBM_FUSED ? (5 * 33554432.0 + 23 * 1048578.0) / 23.0 : 34603010.0;
+        const double hbm_bytes = cb.K == 24 ? k24_step * transmit_bits * frames
                                             : (double)(cb.R + (1 << (cb.K - 1)) / 8) * transmit_bits * frames;
         double upd_mean = 0;
         for (uint64_t v : update_ns) upd_mean += (double)v;

@@ -61,7 +61,12 @@ int vhip_init(vhip_decoder *p, int starting_state);
 /* host-pointer, blocking (copies H2D / D2H around the kernels) */
 int vhip_update(vhip_decoder *p, const unsigned char *syms, int nbits);
 int vhip_chainback(vhip_decoder *p, unsigned char *data, unsigned int nbits, unsigned int endstate);
-/* device-pointer, asynchronous on the handle's stream (inputs already resident in HBM) */
+/* device-pointer, asynchronous on the handle's stream (inputs already resident in HBM).
+ * Exception -- VHIP_KA9Q224: vhip_update_dev BLOCKS the calling thread until the update has been enqueued to its end.  The
+ * K=24 renormalisation (viterbi224_sse2.cpp:226-246) is run speculatively, several multi-step passes ahead of the device,
+ * and the host has to follow the passes' progress word to commit or replay them; with nframes > 1 the frames are spread
+ * over three internal streams driven by three host threads for the duration of the call.  vhip_init and
+ * vhip_chainback_dev stay asynchronous. */
 int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits);
 int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbits, unsigned int endstate);
 void vhip_delete(vhip_decoder *p);
@@ -102,7 +107,8 @@ enum vhip_variant {
     VHIP_VARIANT_LDS = 1,   /* one workgroup per frame, metrics ping-pong in LDS, natural decision rows */
     VHIP_VARIANT_REGS = 2,  /* metrics packed in VGPRs: frames across lanes (K<=9), workgroup per frame (K=15) */
     VHIP_VARIANT_HBM = 3,   /* K=24: metrics tiled through HBM, one launch per trellis step */
-    VHIP_VARIANT_HBM_FUSED = 4 /* K=24: 4 or 7 trellis steps per pass over the metric array (harness polynomials) */
+    VHIP_VARIANT_HBM_FUSED = 4, /* K=24: 4 or 7 trellis steps per pass over the metric array (harness polynomials) */
+    VHIP_VARIANT_HBM_TILED = 5  /* K=24: 9 or 14 steps per pass -- two passes per 23 steps, tiles regrouped through LDS */
 };
 int vhip_set_variant(vhip_decoder *p, int variant);
 int vhip_get_variant(const vhip_decoder *p);

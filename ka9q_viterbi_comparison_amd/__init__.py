@@ -13,6 +13,7 @@ from .decoder import (  # noqa: F401
     VARIANT_REGS,
     VARIANT_HBM,
     VARIANT_HBM_FUSED,
+    VARIANT_HBM_TILED,
     gen_frames_host,
     gen_frames_dev,
     count_bit_errors_dev,

@@ -82,11 +82,14 @@ __device__ __forceinline__ i16x2 acs(i16x2 lower, i16x2 upper, i16x2 &w) {
 // 16-register group (1.5 instructions per register instead of shift + and + or per register).  acc collects the
 // COMPLEMENT of the decisions at bit k15_decision_bit(true, rho, half) (k15_layout.h).
 template <int RE, int NA>
-__device__ __forceinline__ void put_signs(i16x2 we, i16x2 wo, unsigned (&acc)[NA]) {
+__device__ __forceinline__ void put_signs(i16x2 we, i16x2 wo, unsigned (&acc)[NA], const SignMasks &sm) {
     static_assert((RE & 1) == 0, "pairs start at an even register");
     constexpr int i8 = (RE & 15) >> 1;
-    const unsigned P = __builtin_amdgcn_perm(as_u32(wo), as_u32(we), 0x07050301u);
-    acc[RE >> 4] = ((P >> i8) & (0x80808080u >> i8)) | acc[RE >> 4];
+    // v_perm_b32 selectors 8..11 replicate the SIGN of bytes 1 / 3 of either source over the whole destination byte:
+    // one instruction turns the four 16-bit sign bits of (we, wo) into four 0x00 / 0xff bytes, and the pair's bit of each
+    // byte is kept by a mask -- no shift (perm + and + or per register pair)
+    const unsigned P = __builtin_amdgcn_perm(as_u32(wo), as_u32(we), 0x0b0a0908u);
+    acc[RE >> 4] = (P & sm.m[i8]) | acc[RE >> 4];
 }
 
 // spiral615 flavour (spiral/spiral615.cpp:220-227): u8 saturating metrics held as (m<<8)|0xff in 16-bit fields so that
@@ -108,7 +111,7 @@ __device__ __forceinline__ i16x2 madd(i16x2 a, unsigned t) {
 
 // One trellis step at phase PHI on the 128 positions this thread holds.  SP selects the spiral615 arithmetic.
 template <bool SP, int PHI>
-__device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R], unsigned tid, unsigned (&words)[4]) {
+__device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R], unsigned tid, unsigned (&words)[4], const SignMasks &sm) {
     constexpr int b = NB - 1 - PHI;            // position bit paired in this phase
     constexpr bool GA = b >= 7;                // group A: free bits 7..13, thread bits 0..6; group B: the reverse
     constexpr int kf = GA ? b - 7 : b;         // local free-bit index of the paired bit (0 = the half bit)
@@ -200,7 +203,7 @@ __device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R],
                 constexpr int r0 = 2 * decltype(I)::value;
                 i16x2 w0, w1;
                 pair(std::integral_constant<int, r0>{}, w0, w1);
-                put_signs<r0>(w0, w1, acc);
+                put_signs<r0>(w0, w1, acc, sm);
             });
         } else {
             // two butterfly pairs (r0, r1), (r0+1, r1+1) feed the sign-gathering pairs (r0, r0+1) and (r1, r1+1)
@@ -212,8 +215,8 @@ __device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R],
                 i16x2 wa0, wa1, wb0, wb1;
                 pair(std::integral_constant<int, r0>{}, wa0, wa1);
                 pair(std::integral_constant<int, r0 + 1>{}, wb0, wb1);
-                put_signs<r0>(wa0, wb0, acc);
-                put_signs<r1>(wa1, wb1, acc);
+                put_signs<r0>(wa0, wb0, acc, sm);
+                put_signs<r1>(wa1, wb1, acc, sm);
             });
         }
     } else {
@@ -237,7 +240,7 @@ __device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R],
             i16x2 w0, w1;
             half(std::integral_constant<int, r0>{}, w0);
             half(std::integral_constant<int, r0 + 1>{}, w1);
-            if constexpr (!SP) put_signs<r0>(w0, w1, acc);
+            if constexpr (!SP) put_signs<r0>(w0, w1, acc, sm);
         });
     }
 #pragma unroll
@@ -256,6 +259,7 @@ struct Smem {
 template <bool SP>
 __global__ __launch_bounds__(THREADS, 2) void acs_k15_kernel(AcsK15Args a) {
     __shared__ Smem sm;
+    const SignMasks sgm;
     const unsigned tid = threadIdx.x;
     const long f = blockIdx.x;
     const int row0 = a.row0, row_end = a.row0 + a.nsteps;
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(THREADS, 2) void acs_k15_kernel(AcsK15Args a) {
                         sraw[q] = (cur[idx >> 2] >> (8 * (idx & 3))) & 255u;
                     }
                     unsigned words[4];
-                    stage<SP, PHI>(M, sraw, tid, words);
+                    stage<SP, PHI>(M, sraw, tid, words, sgm);
 #pragma unroll
                     for (int w = 0; w < 4; w++) __builtin_nontemporal_store(words[w], drow + w * 128);  // written once, read much later
                     drow += 512;

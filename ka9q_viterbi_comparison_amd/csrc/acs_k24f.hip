@@ -26,6 +26,7 @@
 #include <utility>
 
 #include "k24f_layout.h"
+#include "k24t_layout.h"
 #include "kernels.h"
 #include "viterbi_codes.h"
 
@@ -181,7 +182,7 @@ template <int G, bool FULL>
 __global__ __launch_bounds__(256) void acs_k24f_pass_kernel(const int16_t *oldm, int16_t *__restrict__ newm,
                                                             unsigned char *__restrict__ rows, const unsigned char *syms,
                                                             int rel_row0, int s_lo, int s_hi, int *__restrict__ flags,
-                                                            int *__restrict__ mirror) {
+                                                            K24Report mirror) {
     // rows/syms point at the first row of THIS pass's phase 0 of the group; rel_row0 = that row's index in the call.
     // Stages s in [s_lo, s_hi) of the group run; a pending renormalisation of an earlier row cancels the pass.
     int pending = flags[K24F_PENDING];  // looked at below, behind the metric loads
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void acs_k24f_pass_kernel(const int16_t *oldm,
     // is also why oldm and syms are not __restrict__.
     asm volatile("" : "+s"(pending) : : "memory");
     if (pending != 0 && pending - 1 < rel_row0 + s_lo) {
-        if (mirror && blockIdx.x == 0 && threadIdx.x == 0) *mirror = pending;
+        if (blockIdx.x == 0 && threadIdx.x == 0) k24_report(mirror, pending);
         return;
     }
     sfor<NP>([&](auto I) {
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void acs_k24f_pass_kernel(const int16_t *oldm,
         }
     });
     // the last pass of a host batch also reports the flag to pinned host memory (thread 0 is the only writer of the flag)
-    if (mirror && u == 0) *mirror = pending;
+    if (u == 0) k24_report(mirror, pending);
     if constexpr (G == 4) {
         uint4 *tw = tile + wv * 1024;
 #pragma unroll
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(256) void acs_k24f_pass_kernel(const int16_t *oldm,
 
 // chainback over position-bitmap rows; same walk as chainback_viterbi224_sse2 (viterbi224_sse2.cpp:79-121): no tail
 // skip, emits the bit that falls off the right end of the state, stores a byte only when nbits%8 == 0.
+template <bool TILED>
 __global__ void chainback_k24f_kernel(ChainbackRowsArgs a) {
     const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= a.nframes) return;
@@ -302,7 +304,8 @@ __global__ void chainback_k24f_kernel(ChainbackRowsArgs a) {
         if ((int)i < a.rows_written) {
             const unsigned p = rot == 0 ? e : (((e >> rot) | (e << (NB - rot))) & (N - 1u));
             unsigned widx, wbit;
-            k24f_locate(p, rot == 0 ? NB - 1 : rot - 1, widx, wbit);
+            if constexpr (TILED) k24t_locate(p, rot == 0 ? NB - 1 : rot - 1, widx, wbit);
+            else k24f_locate(p, rot == 0 ? NB - 1 : rot - 1, widx, wbit);
             bit = (reinterpret_cast<const unsigned *>(rows + (size_t)i * (N / 8))[widx] >> wbit) & 1u;
         }
         e = (bit << (K - 2)) | (e >> 1);
@@ -316,7 +319,7 @@ bool k24f_poly_supported(const int *poly) { return poly[0] == k24f::POLY[0] && p
 
 // one pass: stages [s_lo, s_hi) of group g; rows/syms are those of the group's first phase
 hipError_t launch_k24f_pass(int g, const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,
-                            int rel_row0, int s_lo, int s_hi, int *flags, int *mirror, hipStream_t stream) {
+                            int rel_row0, int s_lo, int s_hi, int *flags, K24Report mirror, hipStream_t stream) {
     const dim3 block(256);
     const dim3 grid((k24f::N / (16u * (unsigned)k24f_vw(g))) / 256u);  // 16 vectors of VW positions per thread
     const bool full = s_lo == 0 && s_hi == (g < 4 ? 4 : 7);
@@ -346,8 +349,9 @@ hipError_t launch_k24f_pass(int g, const int16_t *oldm, int16_t *newm, unsigned 
     return hipGetLastError();
 }
 
-hipError_t launch_chainback_k24f(const ChainbackRowsArgs &a, hipStream_t stream) {
-    hipLaunchKernelGGL(k24f::chainback_k24f_kernel, dim3((a.nframes + 63) / 64), dim3(64), 0, stream, a);
+hipError_t launch_chainback_k24f(const ChainbackRowsArgs &a, bool tiled, hipStream_t stream) {
+    if (tiled) hipLaunchKernelGGL(k24f::chainback_k24f_kernel<true>, dim3((a.nframes + 63) / 64), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL(k24f::chainback_k24f_kernel<false>, dim3((a.nframes + 63) / 64), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -13,11 +13,12 @@
 
 #include "k15_layout.h"
 #include "k24f_layout.h"
+#include "k24t_layout.h"
 #include "kernels.h"
 
 namespace vh {
 
-enum { LAY_NATURAL = 0, LAY_K15 = 1, LAY_K24F = 2, LAY_K15_SIGN_BYTES = 3 };
+enum { LAY_NATURAL = 0, LAY_K15 = 1, LAY_K24F = 2, LAY_K15_SIGN_BYTES = 3, LAY_K24T = 4 };
 
 // decision bit of new state `st` at row r for each layout
 template <int LAY, int K>
@@ -38,7 +39,8 @@ __device__ __forceinline__ unsigned fetch_bit(const unsigned char *rows, long r,
             return (w >> k15_decision_bit(LAY == LAY_K15_SIGN_BYTES, rho, h)) & 1u;
         } else {
             unsigned widx, wbit;
-            k24f_locate(p, rot == 0 ? NB - 1 : rot - 1, widx, wbit);
+            if constexpr (LAY == LAY_K24T) k24t_locate(p, rot == 0 ? NB - 1 : rot - 1, widx, wbit);
+            else k24f_locate(p, rot == 0 ? NB - 1 : rot - 1, widx, wbit);
             return (reinterpret_cast<const unsigned *>(rows + r * (long)(N / 8))[widx] >> wbit) & 1u;
         }
     }
@@ -101,6 +103,7 @@ hipError_t launch_chainback_spec(int layout, const ChainbackRowsArgs &a, hipStre
     else if (a.K == 15 && layout == LAY_K15_SIGN_BYTES) hipLaunchKernelGGL((chainback_spec_kernel<LAY_K15_SIGN_BYTES, 15, false>), grid, block, 0, stream, a);
     else if (a.K == 24 && layout == LAY_NATURAL) hipLaunchKernelGGL((chainback_spec_kernel<LAY_NATURAL, 24, true>), grid, block, 0, stream, a);
     else if (a.K == 24 && layout == LAY_K24F) hipLaunchKernelGGL((chainback_spec_kernel<LAY_K24F, 24, true>), grid, block, 0, stream, a);
+    else if (a.K == 24 && layout == LAY_K24T) hipLaunchKernelGGL((chainback_spec_kernel<LAY_K24T, 24, true>), grid, block, 0, stream, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

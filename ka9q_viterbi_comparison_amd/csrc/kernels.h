@@ -6,6 +6,30 @@
 
 namespace vh {
 
+#if defined(__HIPCC__)
+// A constant the compiler must keep in an SGPR instead of re-materialising it as a 32-bit literal at every use: VOP3
+// instructions (v_and_or_b32, v_bitop3_b32, ...) cannot take literals on gfx950, so "(x & LITERAL) | acc" otherwise becomes
+// v_and_b32 + v_or_b32; with the mask in an SGPR it is one v_and_or_b32.
+template <unsigned V>
+__device__ __forceinline__ unsigned sgpr_const() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned r;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "i"(V));
+    return r;
+#else
+    return V;
+#endif
+}
+// the eight sign-byte masks 0x80808080 >> i used by the K=15 / K=24 decision gather (put_signs)
+struct SignMasks {
+    unsigned m[8];
+    __device__ __forceinline__ SignMasks() {
+        m[0] = sgpr_const<0x80808080u>(); m[1] = sgpr_const<0x40404040u>(); m[2] = sgpr_const<0x20202020u>(); m[3] = sgpr_const<0x10101010u>();
+        m[4] = sgpr_const<0x08080808u>(); m[5] = sgpr_const<0x04040404u>(); m[6] = sgpr_const<0x02020202u>(); m[7] = sgpr_const<0x01010101u>();
+    }
+};
+#endif
+
 // ---------------------------------------------------------------- acs_lds.hip (K <= 15, any polynomial)
 struct AcsLdsArgs {
     const unsigned char *syms;  // [nframes][sym_stride] offset-binary u8, step-major
@@ -84,6 +108,18 @@ hipError_t launch_chainback_rows(const ChainbackRowsArgs &a, hipStream_t stream)
 
 // ---------------------------------------------------------------- acs_k24.hip (K = 24, metrics in HBM)
 enum { K24F_PENDING = 0, K24F_MIN = 1, K24F_COUNT = 4 };  // device flag words
+// Progress word of the multi-step K=24 passes, in pinned host memory: every pass stores (seq << 32) | pending flag when its
+// flag-owning thread is done, so the host follows the stream by polling one word instead of waiting on events (an event
+// record / wait per batch of passes put a ~8 us bubble into the stream each time).
+struct K24Report {
+    unsigned long long *word;
+    unsigned seq;
+};
+#if defined(__HIPCC__)
+__device__ __forceinline__ void k24_report(const K24Report &r, int pending) {
+    if (r.word) __hip_atomic_store(r.word, ((unsigned long long)r.seq << 32) | (unsigned)pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
 hipError_t launch_k24_step(const int16_t *oldm, int16_t *newm, unsigned char *row, const unsigned char *d_syms, int step,
                            const int *poly, int *flags, hipStream_t stream);
 hipError_t launch_k24_renorm(int16_t *m, int *flags, hipStream_t stream);  // min-reduce, subtract, clear flags
@@ -92,11 +128,16 @@ hipError_t launch_k24_flags_reset(int *flags, hipStream_t stream);
 // ---------------------------------------------------------------- acs_k24f.hip (K = 24, 4/7 steps per pass)
 bool k24f_poly_supported(const int *poly);
 hipError_t launch_k24f_pass(int g, const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,
-                            int rel_row0, int s_lo, int s_hi, int *flags, int *mirror, hipStream_t stream);
-hipError_t launch_chainback_k24f(const ChainbackRowsArgs &a, hipStream_t stream);
+                            int rel_row0, int s_lo, int s_hi, int *flags, K24Report mirror, hipStream_t stream);
+hipError_t launch_chainback_k24f(const ChainbackRowsArgs &a, bool tiled, hipStream_t stream);  // tiled: k24t_layout.h rows
+
+// ---------------------------------------------------------------- acs_k24t.hip (K = 24, two passes per 23 steps)
+bool k24t_poly_supported(const int *poly);
+hipError_t launch_k24t_pass(int pass, const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,
+                            int rel_row0, int s_lo, int s_hi, int *flags, K24Report mirror, hipStream_t stream);
 
 // ---------------------------------------------------------------- chainback_spec.hip (K = 15 / 24, one wave per frame)
-enum { CB_LAY_NATURAL = 0, CB_LAY_K15 = 1, CB_LAY_K24F = 2, CB_LAY_K15_SIGN_BYTES = 3 };
+enum { CB_LAY_NATURAL = 0, CB_LAY_K15 = 1, CB_LAY_K24F = 2, CB_LAY_K15_SIGN_BYTES = 3, CB_LAY_K24T = 4 };
 hipError_t launch_chainback_spec(int layout, const ChainbackRowsArgs &a, hipStream_t stream);
 
 // ---------------------------------------------------------------- framegen.hip

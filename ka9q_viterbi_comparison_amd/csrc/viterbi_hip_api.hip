@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <thread>
 #include <utility>
@@ -20,6 +21,7 @@
 #include "framegen.h"
 #include "k15_layout.h"
 #include "k24f_layout.h"
+#include "k24t_layout.h"
 #include "kernels.h"
 #include "viterbi_codes.h"
 
@@ -77,9 +79,9 @@ struct vhip_decoder {
     int frames_padded = 0;     // frames rounded up to a whole wave (both decision layouts fit the same buffer)
     static constexpr int K24_WORKERS = 3;            // K=24 with several frames: this many decodes in flight
     hipStream_t aux_stream[K24_WORKERS] = {};
-    int *h_pending = nullptr;                        // K=24: pinned copies of the renormalisation flag, [1 + K24_WORKERS streams][2 batches]
-    int *h_pending_dev = nullptr;                    //        the same words as the device addresses them
-    hipEvent_t k24_ev[1 + K24_WORKERS][2] = {};                    // K=24: "batch finished and its flag copy landed"
+    unsigned long long *h_report = nullptr;          // K=24: pinned progress words (kernels.h K24Report), one per stream
+    unsigned long long *h_report_dev = nullptr;      //        the same words as the device addresses them
+    unsigned k24_seq[1 + K24_WORKERS] = {};          //        last sequence number handed out per stream
     size_t total_bytes = 0;
     // Pipelined decodes (vhip_set_pipeline_depth): `depth` sets of {decision history, metrics, internal stream}.
     // d_dec / d_metrics / pos above always describe the CURRENT set; vhip_init() rotates to the next one.
@@ -207,7 +209,10 @@ int auto_regs_lb(int code, int nframes) {
 }
 
 int auto_variant(const vhip_decoder *p) {
-    if (p->code == VHIP_KA9Q224) return vh::k24f_poly_supported(p->poly) ? VHIP_VARIANT_HBM_FUSED : VHIP_VARIANT_HBM;
+    if (p->code == VHIP_KA9Q224) {
+        if (vh::k24t_poly_supported(p->poly) && !getenv("VHIP_K24_FUSED")) return VHIP_VARIANT_HBM_TILED;
+        return vh::k24f_poly_supported(p->poly) ? VHIP_VARIANT_HBM_FUSED : VHIP_VARIANT_HBM;
+    }
     if (p->K <= 9 && vh::regs_poly_supported(p->code, p->poly)) return VHIP_VARIANT_REGS;
     if ((p->code == VHIP_KA9Q615 || p->code == VHIP_SPIRAL615) && vh::k15_poly_supported(p->poly)) return VHIP_VARIANT_REGS;
     return VHIP_VARIANT_LDS;
@@ -254,92 +259,101 @@ int k24_update_frame(vhip_decoder *p, int f, const unsigned char *d_syms, int st
     return 0;
 }
 
-// K=24 fused passes (acs_k24f.hip): rows are grouped by phase = row mod 23 into passes of 4,4,4,4,7 steps.
+bool k24_multistep(int variant) { return variant == VHIP_VARIANT_HBM_FUSED || variant == VHIP_VARIANT_HBM_TILED; }
+
+// K=24 multi-step passes: rows are grouped by phase = row mod 23 into passes of 4,4,4,4,7 steps (acs_k24f.hip) or of
+// 9,14 steps (acs_k24t.hip).
+//
+// Speculative renormalisation: passes are enqueued ahead of the device, DEPTH at a time, and every pass
+// stores (its sequence number, the sticky flag word) into one pinned host word when its flag-owning thread is done.  The
+// host follows the stream by polling that word -- no event, no stream wait, so nothing but kernels enters the stream -- and
+// commits each pass whose rows lie before the raised row.  When a pass raised the flag, every later pass has returned at
+// once (it sees a flag of an earlier row); the stream is drained, the raising pass is replayed up to the flagged row, the
+// metrics are renormalised and the pipeline restarts behind that row.
 int k24f_update_frame(vhip_decoder *p, int f, const unsigned char *d_syms, int steps, int row0, hipStream_t stream, int *flags) {
+    const bool tiled = p->variant == VHIP_VARIANT_HBM_TILED;
     const size_t NN = p->N;
     int16_t *buf[2] = {p->d_metrics + (size_t)f * 2 * NN, p->d_metrics + (size_t)f * 2 * NN + NN};
     unsigned char *rows = p->d_dec + (size_t)f * p->cap_rows * p->row_bytes;
     int cur = p->k24_cur[f];
-    struct Pass { int g, s_lo, s_hi, rel, in; };  // rel = index in this call of the row of stage s_lo
-    auto group_of = [](int phi, int &first, int &np) {
+    struct Pass { int g, s_lo, s_hi, rel, in; unsigned seq; };  // rel = index in this call of the row of stage s_lo
+    auto group_of = [tiled](int phi, int &first, int &np) {
+        if (tiled) {
+            const int pass = vh::k24t_pass_of_phase(phi);
+            first = vh::k24t_pass_first(pass);
+            np = vh::k24t_pass_nphases(pass);
+            return pass;
+        }
         if (phi < 16) { first = (phi / 4) * 4; np = 4; return phi / 4; }
         first = 16; np = 7; return 4;
     };
-    auto launch = [&](const Pass &q, int *mirror) -> int {
+    const int slot = (int)((flags - p->d_flags) / 4);  // 0: handle stream, 1..: the worker streams
+    volatile unsigned long long *h_word = p->h_report + slot;
+    unsigned long long *d_word = p->h_report_dev + slot;
+    auto launch = [&](const Pass &q, bool report) -> int {
         const long row_g0 = (long)row0 + q.rel - q.s_lo;  // absolute row of the group's phase 0 (may precede row0)
-        HIP_TRY(vh::launch_k24f_pass(q.g, buf[q.in], buf[q.in ^ 1], rows + row_g0 * (long)p->row_bytes,
-                                     d_syms + ((long)q.rel - q.s_lo) * 2, q.rel - q.s_lo, q.s_lo, q.s_hi, flags, mirror, stream));
+        const vh::K24Report rep{report ? d_word : nullptr, q.seq};
+        if (tiled)
+            HIP_TRY(vh::launch_k24t_pass(q.g, buf[q.in], buf[q.in ^ 1], rows + row_g0 * (long)p->row_bytes,
+                                         d_syms + ((long)q.rel - q.s_lo) * 2, q.rel - q.s_lo, q.s_lo, q.s_hi, flags, rep, stream));
+        else
+            HIP_TRY(vh::launch_k24f_pass(q.g, buf[q.in], buf[q.in ^ 1], rows + row_g0 * (long)p->row_bytes,
+                                         d_syms + ((long)q.rel - q.s_lo) * 2, q.rel - q.s_lo, q.s_lo, q.s_hi, flags, rep, stream));
         return 0;
     };
-    // Speculative renormalisation: passes are issued in batches, each followed by an asynchronous copy
-    // of the sticky flag into pinned memory.  Two batches are kept in flight, so the device already runs batch b+1
-    // while the host looks at the flag of batch b; a batch whose flag is clear is committed.  When a flag is raised
-    // every later pass has returned at once (it sees a flag of an earlier row), the stream is drained, the raising
-    // pass is replayed up to the flagged row, the metrics are renormalised and the pipeline restarts behind that row.
-    constexpr int BATCH = 12;
-    const int slot = (int)((flags - p->d_flags) / 4);  // 0: handle stream, 1/2: the two worker streams
-    struct Batch { std::vector<Pass> passes; int t_end = 0, cur_end = 0; };
-    int t = 0;  // next row of this call
+    // passes kept enqueued: enough work (>= ~100 us) for the host to see a report and enqueue the next pass, no more --
+    // every pass behind a raised flag is cancelled work (it still streams part of its tile in)
+    const size_t DEPTH = tiled ? 6 : 12;
+    std::deque<Pass> inflight;
+    int t = 0;        // rows of this call committed so far
+    int tt = 0, c = cur;  // next row / buffer to enqueue
+    unsigned &seq = p->k24_seq[slot];
     while (t < steps) {
-        Batch q[2];
-        int tt = t, c = cur;
-        auto enqueue = [&](int k) -> int {
-            Batch &b = q[k];
-            b.passes.clear();
-            while (tt < steps && (int)b.passes.size() < BATCH) {
-                const int phi = (row0 + tt) % 23;
-                int first, np;
-                const int g = group_of(phi, first, np);
-                Pass ps{g, phi - first, std::min(np, phi - first + (steps - tt)), tt, c};
-                const int adv = ps.s_hi - ps.s_lo;
-                const bool last = tt + adv >= steps || (int)b.passes.size() + 1 == BATCH;
-                // the last pass of the batch reports the flag word straight into pinned host memory
-                if (launch(ps, last ? p->h_pending_dev + slot * 2 + k : nullptr) != 0) return -1;
-                b.passes.push_back(ps);
-                tt += adv;
-                c ^= 1;
-            }
-            b.t_end = tt;
-            b.cur_end = c;
-            HIP_TRY(hipEventRecord(p->k24_ev[slot][k], stream));
-            return 0;
-        };
-        int inflight = 0, k = 0;
-        if (enqueue(0) != 0) return -1;
-        inflight++;
-        if (tt < steps) {
-            if (enqueue(1) != 0) return -1;
-            inflight++;
+        while (inflight.size() < DEPTH && tt < steps) {
+            const int phi = (row0 + tt) % 23;
+            int first, np;
+            const int g = group_of(phi, first, np);
+            Pass ps{g, phi - first, std::min(np, phi - first + (steps - tt)), tt, c, ++seq};
+            if (launch(ps, true) != 0) return -1;
+            inflight.push_back(ps);
+            tt += ps.s_hi - ps.s_lo;
+            c ^= 1;
         }
-        while (inflight > 0) {
-            HIP_TRY(hipEventSynchronize(p->k24_ev[slot][k]));
-            const int pending = p->h_pending[slot * 2 + k];
-            if (pending == 0) {
-                t = q[k].t_end;
-                cur = q[k].cur_end;
-                inflight--;
-                if (tt < steps) {
-                    if (enqueue(k) != 0) return -1;
-                    inflight++;
-                }
-                k ^= 1;
-                continue;
+        // wait for the oldest pass in flight to report
+        const Pass &front = inflight.front();
+        unsigned long long w;
+        unsigned spins = 0;
+        while ((int)((unsigned)((w = *h_word) >> 32) - front.seq) < 0) {
+            if ((++spins & 0xfffu) == 0) {
+                // a device fault would leave the word unchanged for ever: ask the runtime now and then
+                const hipError_t qe = hipStreamQuery(stream);
+                if (qe != hipSuccess && qe != hipErrorNotReady) return fail("K=24: stream failed while waiting for a pass", qe);
+                if (qe == hipSuccess && (int)((unsigned)(*h_word >> 32) - front.seq) < 0) return fail("K=24: pass finished without reporting");
             }
-            HIP_TRY(hipStreamSynchronize(stream));  // the younger batch only holds passes that returned at once
-            const int rr = pending - 1;             // renormalise after this row of the call
-            const Pass *hit = nullptr;
-            for (const Pass &ps : q[k].passes)
-                if (rr >= ps.rel && rr < ps.rel + (ps.s_hi - ps.s_lo)) hit = &ps;
-            if (!hit) return fail("K=24 fused: renormalisation flag out of range");
-            HIP_TRY(vh::launch_k24_flags_reset(flags, stream));
-            Pass redo = *hit;
-            redo.s_hi = redo.s_lo + (rr - redo.rel) + 1;  // replay the raising pass up to and including row rr
-            if (launch(redo, nullptr) != 0) return -1;
-            cur = redo.in ^ 1;
-            HIP_TRY(vh::launch_k24_renorm(buf[cur], flags, stream));  // min-reduce, wrapping subtract, clear flags
-            t = rr + 1;
-            break;  // restart the pipeline behind the renormalised row
+            std::this_thread::yield();
         }
+        const int pending = (int)(unsigned)(w & 0xffffffffull);
+        const int adv = front.s_hi - front.s_lo;
+        if (pending == 0 || pending - 1 >= front.rel + adv) {  // no flag, or raised by a later row: this pass stands
+            t = front.rel + adv;
+            cur = front.in ^ 1;
+            inflight.pop_front();
+            continue;
+        }
+        const int rr = pending - 1;  // renormalise after this row of the call
+        if (rr < front.rel) return fail("K=24: renormalisation flag out of range");
+        HIP_TRY(hipStreamSynchronize(stream));  // the younger passes have returned at once
+        HIP_TRY(vh::launch_k24_flags_reset(flags, stream));
+        Pass redo = front;
+        redo.s_hi = redo.s_lo + (rr - redo.rel) + 1;  // replay the raising pass up to and including row rr
+        redo.seq = ++seq;
+        if (launch(redo, false) != 0) return -1;
+        cur = redo.in ^ 1;
+        HIP_TRY(vh::launch_k24_renorm(buf[cur], flags, stream));  // min-reduce, wrapping subtract, clear flags
+        t = rr + 1;
+        tt = t;
+        c = cur;
+        inflight.clear();  // restart the pipeline behind the renormalised row
     }
     p->k24_cur[f] = cur;
     return 0;
@@ -411,9 +425,9 @@ vhip_decoder *vhip_create(int code, const int *poly, int len, int nframes) {
     if (code == VHIP_KA9Q224 && nframes > 1)
         for (int w = 0; w < vhip_decoder::K24_WORKERS && e == hipSuccess; w++) e = hipStreamCreateWithFlags(&p->aux_stream[w], hipStreamNonBlocking);
     if (code == VHIP_KA9Q224) {
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&p->h_pending), sizeof(int) * 2 * (1 + vhip_decoder::K24_WORKERS), hipHostMallocMapped);
-        if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_pending_dev), p->h_pending, 0);
-        for (int i = 0; i < 2 * (1 + vhip_decoder::K24_WORKERS) && e == hipSuccess; i++) e = hipEventCreateWithFlags(&p->k24_ev[i / 2][i % 2], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&p->h_report), sizeof(unsigned long long) * 8 * (1 + vhip_decoder::K24_WORKERS), hipHostMallocMapped);
+        if (e == hipSuccess) memset(p->h_report, 0, sizeof(unsigned long long) * 8 * (1 + vhip_decoder::K24_WORKERS));
+        if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_report_dev), p->h_report, 0);
     }
     if (e != hipSuccess) {
         fail("create: stream", e);
@@ -456,9 +470,7 @@ void vhip_delete(vhip_decoder *p) {
     if (p->d_flags) (void)hipFree(p->d_flags);
     for (int w = 0; w < vhip_decoder::K24_WORKERS; w++)
         if (p->aux_stream[w]) (void)hipStreamDestroy(p->aux_stream[w]);
-    for (int i = 0; i < 2 * (1 + vhip_decoder::K24_WORKERS); i++)
-        if (p->k24_ev[i / 2][i % 2]) (void)hipEventDestroy(p->k24_ev[i / 2][i % 2]);
-    if (p->h_pending) (void)hipHostFree(p->h_pending);
+    if (p->h_report) (void)hipHostFree(p->h_report);
     if (p->d_syms_stage) (void)hipFree(p->d_syms_stage);
     if (p->d_data_stage) (void)hipFree(p->d_data_stage);
     delete p;
@@ -564,7 +576,9 @@ int vhip_set_variant(vhip_decoder *p, int variant) {
     variant &= 0xff;
     if (variant == VHIP_VARIANT_AUTO) variant = auto_variant(p);
     if (p->code == VHIP_KA9Q224) {
-        if (variant != VHIP_VARIANT_HBM && variant != VHIP_VARIANT_HBM_FUSED) return fail("set_variant: K=24 supports only the HBM variants");
+        if (variant != VHIP_VARIANT_HBM && !k24_multistep(variant)) return fail("set_variant: K=24 supports only the HBM variants");
+        if (variant == VHIP_VARIANT_HBM_TILED && !vh::k24t_poly_supported(p->poly))
+            return fail("set_variant: the tiled K=24 kernel needs the harness polynomials");
         if (variant == VHIP_VARIANT_HBM_FUSED && !vh::k24f_poly_supported(p->poly))
             return fail("set_variant: the fused K=24 kernel needs the harness polynomials");
     } else if (variant == VHIP_VARIANT_REGS && p->K == 15) {
@@ -632,7 +646,7 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
         ~TimeScope() { timing_end(e1, st); }
     } time_scope{timing_begin(p, p->t_upd, p->run_stream()), p->run_stream()};
     if (p->code == VHIP_KA9Q224) {
-        if (p->variant == VHIP_VARIANT_HBM_FUSED && p->nframes > 1) {
+        if (k24_multistep(p->variant) && p->nframes > 1) {
             // A single K=24 decode leaves the chip under-occupied between its load/compute/store phases (two concurrent
             // decodes run 1.47x faster than two serial ones), so K24_WORKERS frames are decoded at a time: one host thread
             // each, with its own stream and flag words, frames interleaved between them.
@@ -655,7 +669,7 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
                 if (rcs[w] != 0) return fail(errs[w].empty() ? "K=24 worker failed" : errs[w].c_str());
         } else {
             for (int f = 0; f < p->nframes; f++) {
-                const int rc = p->variant == VHIP_VARIANT_HBM_FUSED
+                const int rc = k24_multistep(p->variant)
                                    ? k24f_update_frame(p, f, d_syms + (size_t)f * sym_stride, steps, row0, p->stream, p->d_flags)
                                    : k24_update_frame(p, f, d_syms + (size_t)f * sym_stride, steps, row0);
                 if (rc != 0) return -1;
@@ -711,7 +725,8 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
         hipStream_t st;
         ~TimeScope() { timing_end(e1, st); }
     } time_scope{timing_begin(p, p->t_cb, p->run_stream()), p->run_stream()};
-    if (p->variant == VHIP_VARIANT_HBM_FUSED) {
+    if (k24_multistep(p->variant)) {
+        const bool tiled = p->variant == VHIP_VARIANT_HBM_TILED;
         vh::ChainbackRowsArgs a;
         a.dec = p->d_dec;
         a.cap_rows = p->cap_rows;
@@ -723,8 +738,8 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
         a.endstate = endstate;
         a.K = p->K;
         a.k224 = 1;
-        if (getenv("VHIP_CHAINBACK_SIMPLE")) HIP_TRY(vh::launch_chainback_k24f(a, p->stream));
-        else HIP_TRY(vh::launch_chainback_spec(vh::CB_LAY_K24F, a, p->stream));
+        if (getenv("VHIP_CHAINBACK_SIMPLE")) HIP_TRY(vh::launch_chainback_k24f(a, tiled, p->stream));
+        else HIP_TRY(vh::launch_chainback_spec(tiled ? vh::CB_LAY_K24T : vh::CB_LAY_K24F, a, p->stream));
         return 0;
     }
     if (p->variant == VHIP_VARIANT_REGS && p->K == 15) {
@@ -818,8 +833,9 @@ int vhip_read_decision_rows(vhip_decoder *p, int frame, int row0, int nrows, uns
     if (frame < 0 || frame >= p->nframes || row0 < 0 || nrows < 0 || row0 + nrows > p->cap_rows)
         return fail("read_decision_rows: out of range");
     if (sync_all(p) != 0) return -1;
-    if (p->variant == VHIP_VARIANT_HBM_FUSED) {
-        // position bitmap of acs_k24f.hip -> natural bitmap
+    if (k24_multistep(p->variant)) {
+        // position bitmap of acs_k24f.hip / acs_k24t.hip -> natural bitmap
+        const bool tiled = p->variant == VHIP_VARIANT_HBM_TILED;
         const int NB = 23;
         std::vector<unsigned char> raw(p->row_bytes);
         memset(out, 0, (size_t)nrows * p->row_bytes);
@@ -831,7 +847,8 @@ int vhip_read_decision_rows(vhip_decoder *p, int frame, int row0, int nrows, uns
             for (unsigned n = 0; n < p->N; n++) {
                 const unsigned pos = rot == 0 ? n : (((n >> rot) | (n << (NB - rot))) & (p->N - 1));
                 unsigned widx, wbit;
-                vh::k24f_locate(pos, phi, widx, wbit);
+                if (tiled) vh::k24t_locate(pos, phi, widx, wbit);
+                else vh::k24f_locate(pos, phi, widx, wbit);
                 if ((rw[widx] >> wbit) & 1u) o[n >> 3] |= (unsigned char)(1u << (n & 7));
             }
         }
@@ -894,8 +911,8 @@ int vhip_read_metrics(vhip_decoder *p, int frame, int32_t *out) {
                              ? p->d_metrics + ((size_t)frame * 2 + p->k24_cur[frame]) * p->N
                              : p->d_metrics + (size_t)frame * p->N;
     HIP_TRY(hipMemcpy(tmp.data(), src, (size_t)p->N * sizeof(int16_t), hipMemcpyDeviceToHost));
-    if (p->variant == VHIP_VARIANT_HBM_FUSED) {
-        // the fused K=24 kernels keep the rotating layout between calls: position q holds state rotl^(pos mod 23)(q)
+    if (k24_multistep(p->variant)) {
+        // the multi-step K=24 kernels keep the rotating layout between calls: position q holds state rotl^(pos mod 23)(q)
         const int NB = 23, rot = p->pos % NB;
         for (unsigned q = 0; q < p->N; q++) {
             const unsigned st = rot == 0 ? q : (((q << rot) | (q >> (NB - rot))) & (p->N - 1));

@@ -10,7 +10,7 @@ import torch
 
 from common import spec_of
 from ka9q_viterbi_comparison_amd import HipViterbi, codes as C, count_bit_errors_dev, gen_frames_dev, noise_q12
-from ka9q_viterbi_comparison_amd import VARIANT_HBM, VARIANT_HBM_FUSED, VARIANT_LDS, VARIANT_REGS
+from ka9q_viterbi_comparison_amd import VARIANT_HBM, VARIANT_HBM_FUSED, VARIANT_HBM_TILED, VARIANT_LDS, VARIANT_REGS
 from oracle_lib import OracleDecoder
 
 pytestmark = pytest.mark.gpu
@@ -90,11 +90,11 @@ def test_config4_k24_long_frame(bits):
     spec, d_payload, d_syms, d_out = decode_batch("224", 1, bits, hard=True, cb_bits=steps)
     assert count_bit_errors_dev(d_out, d_payload, bits // 8) == 0
     outs = []
-    for variant in (VARIANT_HBM, VARIANT_HBM_FUSED):
+    for variant in (VARIANT_HBM, VARIANT_HBM_FUSED, VARIANT_HBM_TILED):
         spec, d_payload, d_syms, d_out = decode_batch("224", 1, bits, hard=False, variant=variant, cb_bits=steps)
         outs.append(d_out.cpu().numpy().copy())
         assert count_bit_errors_dev(d_out, d_payload, bits // 8) == 0  # K=24 at 4 dB: error free
-    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
 @pytest.mark.parametrize("name,frames", [("47", 65536), ("29", 32768), ("49", 32768)])

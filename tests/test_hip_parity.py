@@ -7,7 +7,7 @@ import pytest
 
 from common import GPU_CODES, bit_errors, frames, spec_of
 from ka9q_viterbi_comparison_amd import HipViterbi, codes as C
-from ka9q_viterbi_comparison_amd import VARIANT_AUTO, VARIANT_HBM, VARIANT_HBM_FUSED, VARIANT_LDS, VARIANT_REGS
+from ka9q_viterbi_comparison_amd import VARIANT_AUTO, VARIANT_HBM, VARIANT_HBM_FUSED, VARIANT_HBM_TILED, VARIANT_LDS, VARIANT_REGS
 from oracle_lib import OracleDecoder
 
 pytestmark = pytest.mark.gpu
@@ -20,7 +20,7 @@ def regs(lb):
 
 def variants_for(code):
     if code == C.KA9Q224:
-        return [VARIANT_HBM, VARIANT_HBM_FUSED]
+        return [VARIANT_HBM, VARIANT_HBM_FUSED, VARIANT_HBM_TILED]
     if code == C.KA9Q615:
         return [VARIANT_LDS, VARIANT_REGS]
     if code == C.SPIRAL615:
@@ -159,7 +159,7 @@ def test_endstate_start_state_and_ragged_bits(code, variant):
         dec.close()
 
 
-@pytest.mark.parametrize("variant", [VARIANT_HBM, VARIANT_HBM_FUSED])
+@pytest.mark.parametrize("variant", [VARIANT_HBM, VARIANT_HBM_FUSED, VARIANT_HBM_TILED])
 def test_k24_chainback_variants(variant):
     """chainback_viterbi224_sse2 has no tail skip: pin both the harness call (nbits) and the
     correct one (nbits+K-1)."""
@@ -203,7 +203,7 @@ def test_k615_forced_renormalisation_and_return_value():
     dec.close()
 
 
-@pytest.mark.parametrize("variant", [VARIANT_HBM, VARIANT_HBM_FUSED])
+@pytest.mark.parametrize("variant", [VARIANT_HBM, VARIANT_HBM_FUSED, VARIANT_HBM_TILED])
 def test_k24_renormalisation_and_incremental(variant):
     """A K=24 frame long enough to renormalise (viterbi224_sse2.cpp:226-246), fed in ragged pieces so that the
     speculative replay and the phase bookkeeping of the fused passes are exercised; two frames per handle."""
@@ -242,13 +242,13 @@ def test_k24_many_frames_per_handle():
     steps = B * 8 + spec.K - 1
     payload, syms = frames(code, 31, nframes, B, spec.ebn0_db)
     out = {}
-    for variant in (VARIANT_HBM_FUSED, VARIANT_HBM):
+    for variant in (VARIANT_HBM_TILED, VARIANT_HBM_FUSED, VARIANT_HBM):
         dec = HipViterbi("224", steps, nframes=nframes, variant=variant)
         dec.reset()
         dec.update(syms)
         data, _ = dec.chainback(steps)
         out[variant] = (data.copy(), np.stack([dec.metrics(f) for f in range(nframes)]))
-        if variant == VARIANT_HBM_FUSED:
+        if variant != VARIANT_HBM:
             for f in (0, nframes - 1):
                 ref = oracle_decode(code, syms[f], steps, steps)
                 assert ref["renorms"] >= 1
@@ -257,10 +257,11 @@ def test_k24_many_frames_per_handle():
                 for r in (0, 22, 23, 200, steps - 1):
                     assert np.array_equal(dec.decision_rows(f, r, 1), ref["rows"][r:r + 1]), f"frame {f} row {r}"
         dec.close()
-    assert np.array_equal(out[VARIANT_HBM_FUSED][0], out[VARIANT_HBM][0])
-    assert np.array_equal(out[VARIANT_HBM_FUSED][1], out[VARIANT_HBM][1])
+    for v in (VARIANT_HBM_FUSED, VARIANT_HBM_TILED):
+        assert np.array_equal(out[v][0], out[VARIANT_HBM][0])
+        assert np.array_equal(out[v][1], out[VARIANT_HBM][1])
     for f in range(nframes):
-        assert bit_errors(out[VARIANT_HBM_FUSED][0][f][:B], payload[f]) == 0
+        assert bit_errors(out[VARIANT_HBM_TILED][0][f][:B], payload[f]) == 0
 
 
 @pytest.mark.parametrize("name,depth,nframes", [("27", 2, 300), ("27", 3, 70), ("47", 2, 130), ("29", 2, 70), ("615", 2, 3), ("spiral615", 2, 2)])
@@ -465,7 +466,7 @@ def test_arbitrary_polynomials(code):
             o.close()
         dec.close()
         with pytest.raises(VhipError):
-            HipViterbi(spec.name, steps, nframes=1, poly=poly, variant=VARIANT_HBM_FUSED if spec.K == 24 else VARIANT_REGS)
+            HipViterbi(spec.name, steps, nframes=1, poly=poly, variant=VARIANT_HBM_TILED if spec.K == 24 else VARIANT_REGS)
 
 
 @pytest.mark.parametrize("code,variant", [(C.KA9Q27, regs(0)), (C.SPIRAL47, regs(0)), (C.KA9Q27, regs(2)), (C.KA9Q29, regs(1)), (C.SPIRAL49, regs(0))])

@@ -1,5 +1,5 @@
 """The decision-row layouts shared by the ACS kernels, the chainback kernels and the host-side row conversion
-(csrc/k15_layout.h, csrc/k24f_layout.h) must be bijections: every state's decision has exactly one bit of the row.
+(csrc/k15_layout.h, csrc/k24f_layout.h, csrc/k24t_layout.h) must be bijections: every state's decision has exactly one bit of the row.
 The headers are plain C++ on the host side, so this compiles a small checker with g++ (no GPU, no HIP)."""
 import os
 import subprocess
@@ -13,6 +13,7 @@ CHECKER = r"""
 #include <vector>
 #include "k15_layout.h"
 #include "k24f_layout.h"
+#include "k24t_layout.h"
 int main() {
     // K=15: 16 registers x 2 halves -> 32 distinct bits, both bit orders
     for (int sb = 0; sb < 2; sb++) {
@@ -56,6 +57,39 @@ int main() {
             const unsigned wpt = (16u << vh::k24f_lw(g)) / 32u;
             if (w != u * wpt || b != vh::k24f_decision_bit(0, 0)) { printf("k24f group %d: thread base of %u\n", g, u); return 1; }
         }
+    }
+    // K=24 two-pass layout: every phase's position -> (word, bit) map covers the row exactly once; thread_base | spos(rho)
+    // | half reproduces the position a (tile, thread, register, field) holds; register bits match the paired position bits
+    for (int phi = 0; phi < 23; phi++) {
+        const int g = vh::k24t_group_of_phase(phi);
+        if (phi < vh::k24t_first_phase(g) || phi >= vh::k24t_first_phase(g) + vh::k24t_nphases(g)) { printf("k24t group range\n"); return 1; }
+        const int b = 22 - phi;
+        if (b >= 1) {
+            const int rb = vh::k24t_regbit(g, b);
+            if (rb < 0 || (1 << rb) >= vh::k24t_nr(g) || vh::k24t_spos(g, 1u << rb) != (1u << b)) { printf("k24t regbit phase %d\n", phi); return 1; }
+        }
+        if (phi != vh::k24t_first_phase(g)) continue;  // one full sweep per group is enough for the bijection
+        std::vector<unsigned> row(1u << 18, 0u);
+        for (unsigned p = 0; p < (1u << 23); p++) {
+            unsigned w, bit;
+            vh::k24t_locate(p, phi, w, bit);
+            if (w >= row.size() || bit >= 32 || ((row[w] >> bit) & 1u)) { printf("k24t group %d: clash at position %u\n", g, p); return 1; }
+            row[w] |= 1u << bit;
+        }
+        const unsigned tiles = g <= vh::K24T_H2 ? 256u : 512u, threads = (unsigned)vh::k24t_threads(g), nr = (unsigned)vh::k24t_nr(g);
+        if ((unsigned long long)tiles * threads * nr * 2ull != (1ull << 23)) { printf("k24t group %d: size\n", g); return 1; }
+        for (unsigned tile = 0; tile < tiles; tile += 37)
+            for (unsigned tid = 0; tid < threads; tid += 13)
+                for (unsigned rho = 0; rho < nr; rho += 5)
+                    for (unsigned h = 0; h < 2; h++) {
+                        const unsigned p = vh::k24t_thread_base(g, tile, tid) | vh::k24t_spos(g, rho) | h;
+                        unsigned w, bit;
+                        vh::k24t_locate(p, phi, w, bit);
+                        if (w != (tile * threads + tid) * (nr / 16) + (rho >> 4) || bit != vh::k24t_decision_bit(rho, h)) {
+                            printf("k24t group %d: tile %u tid %u rho %u half %u\n", g, tile, tid, rho, h);
+                            return 1;
+                        }
+                    }
     }
     printf("ok\n");
     return 0;

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Where does a K=24 tiled pass spend its time?  Kernel trace of bench.py --code 224 in the three timing modes of
+# acs_k24t.hip (VHIP_K24T_MODE: 0 = real, 1 = data movement only, 2 = trellis stages + row stores only; modes 1 and 2
+# produce wrong results by design).  Run on the GPU box from the repo root.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/${1:-k24t_probe}
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+for m in ${MODES:-0 1 2 3}; do
+  VHIP_K24T_MODE=$m timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/mode$m -o s --output-format csv -- python3 $R/bench.py --code 224 --no-cpu-baseline --steps 2 --warmup 1 > $O/mode$m.log 2>&1
+  echo "mode $m:"; grep -E "pass_[hl]_kernel<true" $O/mode$m/s_kernel_stats.csv | awk -F'","' '{print substr($1,1,60), "calls", $2, "avg_ns", $4, "max_ns", $7}'
+done
