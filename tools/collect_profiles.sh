@@ -1,21 +1,62 @@
 #!/bin/bash
-# Collect the rocprofv3 evidence kept under profiles/ (run on the GPU box from the repo root):
-#   kernel-trace stats of the default bench and of the K=15 / K=24 configs, VALU-instruction and HBM-traffic PMC passes.
-# Counter passes run on their own (no trace domains besides --kernel-trace), one counter set per run.
-set -e
+# Collect the evidence kept under profiles/ (run on the GPU box from the repo root):  tools/collect_profiles.sh r02
+#   1. rocprofv3 --kernel-trace --stats of the default bench command (what the driver runs) and of the serial schedule,
+#      the K=15 and the K=24 configs
+#   2. PMC passes, each on its own (MI355X_MICROARCH.md §HBM / §PMC slots: FETCH_SIZE and WRITE_SIZE do not fit one pass):
+#      SQ_INSTS_VALU..., FETCH_SIZE, WRITE_SIZE for K=7 / K=15 / K=24; summarised into profiles/{traffic,valu}_<code>.json
+#      together with a fingerprint of the kernel sources (tools/kernel_hash.py) so that bench.py can tell when they are stale
+#   3. the per-code sweep with the CPU baseline, the config-5 shard-size lines, the harness in its default and in its
+#      reference-methodology (--host-api) mode
+# The program goes directly after `--` (no env / bash -c hop).
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/final
-mkdir -p $O
+O=$R/gpurun_out/$TAG
+P=$R/profiles
+mkdir -p $O $P
 cd /tmp && export TMPDIR=/tmp
+prof() { # name, code, extra bench args...
+  local name=$1 code=$2; shift 2
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_$name -o s --output-format csv -- python3 $R/bench.py --code $code --no-cpu-baseline "$@" > $O/stats_$name.json 2> $O/stats_$name.err
+  cp $O/stats_$name/s_kernel_stats.csv $P/${TAG}_${name}_kernel_stats.csv 2>/dev/null
+  tail -n 1 $O/stats_$name.json > $P/${TAG}_${name}_bench_under_rocprof.json
+  echo "stats $name done"
+}
+prof viterbi27 27 --steps 20 --warmup 3
+prof viterbi27_serial 27 --steps 20 --warmup 3 --no-pipeline
+prof viterbi615 615 --steps 5 --warmup 1
+prof viterbi224 224 --steps 5 --warmup 1
+pmc() { # name, code, counters...
+  local name=$1 code=$2; shift 2
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" -d $O/pmc_$name -o c --output-format csv -- python3 $R/bench.py --code $code --no-cpu-baseline --no-pipeline --steps 2 --warmup 1 > $O/pmc_$name.log 2>&1
+  echo "pmc $name done"
+}
 for c in 27 615 224; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_$c -o s --output-format csv -- python3 $R/bench.py --code $c --no-cpu-baseline --no-pipeline --steps 5 --warmup 1 > $O/stats_$c.log 2>&1
-  echo "stats $c done"
+  pmc fetch_$c $c FETCH_SIZE
+  pmc write_$c $c WRITE_SIZE
 done
-for c in 27 615; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE -d $O/valu_$c -o v --output-format csv -- python3 $R/bench.py --code $c --no-cpu-baseline --no-pipeline --steps 2 --warmup 1 > $O/valu_$c.log 2>&1
-  echo "valu $c done"
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch_$c -o f --output-format csv -- python3 $R/bench.py --code $c --no-cpu-baseline --no-pipeline --steps 2 --warmup 1 > $O/fetch_$c.log 2>&1
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write_$c -o w --output-format csv -- python3 $R/bench.py --code $c --no-cpu-baseline --no-pipeline --steps 2 --warmup 1 > $O/write_$c.log 2>&1
-  echo "traffic $c done"
-done
-ls -R $O | head -60
+for c in 27 615; do pmc valu_$c $c SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE; done
+cd $R
+python3 tools/summarize_pmc.py 27 $O/pmc_fetch_27/c_counter_collection.csv $O/pmc_write_27/c_counter_collection.csv acs_regs_kernel
+python3 tools/summarize_pmc.py 615 $O/pmc_fetch_615/c_counter_collection.csv $O/pmc_write_615/c_counter_collection.csv acs_k15_kernel
+python3 tools/summarize_pmc.py 224 $O/pmc_fetch_224/c_counter_collection.csv $O/pmc_write_224/c_counter_collection.csv acs_k24t_pass
+ms27=$(python3 -c "import json;print(json.load(open('$P/${TAG}_viterbi27_serial_bench_under_rocprof.json'))['update_ms'])")
+ms615=$(python3 -c "import json;print(json.load(open('$P/${TAG}_viterbi615_bench_under_rocprof.json'))['roofline']['alone']['update_ms'])")
+python3 tools/summarize_valu.py 27 $O/pmc_valu_27/c_counter_collection.csv acs_regs_kernel $ms27
+python3 tools/summarize_valu.py 615 $O/pmc_valu_615/c_counter_collection.csv acs_k15_kernel $ms615
+for c in 27 615; do cp $O/pmc_valu_$c/c_counter_collection.csv $P/${TAG}_viterbi${c}_pmc_valu_counter_collection.csv; done
+for c in 27 615 224; do for k in fetch write; do cp $O/pmc_${k}_$c/c_counter_collection.csv $P/${TAG}_viterbi${c}_pmc_${k}_counter_collection.csv; done; done
+# 3. sweep, shard-size lines, harness
+python3 tools/sweep.py --out $P/${TAG}_sweep --steps 20 --cpu > $O/sweep.log 2>&1
+echo "sweep done"
+: > $P/${TAG}_config5_shard_size.jsonl
+for c in 27 47 29 49; do python3 bench.py --code $c --frames 131072 --steps 5 --warmup 1 --no-cpu-baseline 2>> $O/shard.err | tail -n 1 >> $P/${TAG}_config5_shard_size.jsonl; done
+python3 bench.py --code 615 --frames 131072 --steps 2 --warmup 1 --no-cpu-baseline 2>> $O/shard.err | tail -n 1 >> $P/${TAG}_config5_shard_size.jsonl
+python3 bench.py --code 224 --frames 12 --payload-bits 64 --steps 2 --warmup 1 --no-cpu-baseline 2>> $O/shard.err | tail -n 1 >> $P/${TAG}_config5_shard_size.jsonl
+echo "shard-size lines done"
+./harness/viterbi_bench -t 1.0 -n 8 -o $P/${TAG}_harness_default.json > $O/harness.log 2>&1
+./harness/viterbi_bench -t 1.0 -n 8 --host-api --hard -o $P/${TAG}_harness_host_1frame.json >> $O/harness.log 2>&1
+python3 tools/tabulate_results.py $P/${TAG}_harness_default.json $P/${TAG}_harness_host_1frame.json > $P/${TAG}_harness_tables.md 2>> $O/harness.log
+./tools/valu_rate > $P/${TAG}_valu_rate.txt 2>&1
+./tools/sstore_rate > $P/${TAG}_sstore_rate.txt 2>&1
+./tools/icache_probe > $P/${TAG}_icache_probe.txt 2>&1
+ls $P | grep $TAG

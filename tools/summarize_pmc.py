@@ -23,8 +23,22 @@ def mean_counter(path, kernel_sub, counter):
 
 def main():
     code, fetch_csv, write_csv, ksub = sys.argv[1:5]
-    f, nf = mean_counter(fetch_csv, ksub, "FETCH_SIZE")
-    w, nw = mean_counter(write_csv, ksub, "WRITE_SIZE")
+    if code == "224":
+        # K=24: one update is many pass launches.  Mean counters of the full-pass kernels of each kind (H: 9 steps, L: 14
+        # steps), added up per 23-step period and scaled to the bench's 2071-step update.
+        steps = 2048 + 23
+        f = w = 0.0
+        nf = nw = 0
+        for kind in ("pass_h_kernel<true", "pass_l_kernel<true"):
+            fk, n1 = mean_counter(fetch_csv, kind, "FETCH_SIZE")
+            wk, n2 = mean_counter(write_csv, kind, "WRITE_SIZE")
+            f += fk * steps / 23.0
+            w += wk * steps / 23.0
+            nf += n1
+            nw += n2
+    else:
+        f, nf = mean_counter(fetch_csv, ksub, "FETCH_SIZE")
+        w, nw = mean_counter(write_csv, ksub, "WRITE_SIZE")
     from kernel_hash import kernel_family, kernel_source_hash
     from ka9q_viterbi_comparison_amd.codes import CODES
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs bench.py for every code (BASELINE.json config 5 style sweep on one GPU) and writes the JSON lines plus a
-markdown table.   python tools/sweep.py [--out profiles/r01_sweep] [--steps 20] [--cpu]"""
+markdown table.   python tools/sweep.py [--out profiles/r02_sweep] [--steps 20] [--cpu]"""
 import argparse
 import json
 import os
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r01_sweep"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_sweep"))
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--cpu", action="store_true", help="also time the CPU baseline per code (adds ~12 s each)")
     ap.add_argument("--codes", default="27,47,29,49,615,224,spiral27,spiral29,spiral615")
