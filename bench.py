@@ -149,14 +149,16 @@ class HipShard:
         # The decision history (N/8 bytes per frame-step, times the pipeline depth) must fit in HBM next to the symbols:
         # large K=15 batches are decoded in chunks of frames that reuse one handle (SURVEY.md §7 "K=15 capacity"); a
         # step still covers all frames.
-        self.depth = 1 if spec.K == 24 else max(1, args.pipeline_depth)
-        dec_bytes_per_frame = (self.nsteps + spec.K) * ((1 << (spec.K - 1)) // 8) * self.depth
+        self.windowed = bool(getattr(args, "windowed", False))
+        self.depth = 1 if (spec.K == 24 or self.windowed) else max(1, args.pipeline_depth)
+        dec_bytes_per_frame = (64 if self.windowed else self.nsteps + spec.K) * ((1 << (spec.K - 1)) // 8) * self.depth
         budget = int(args.hbm_budget_gb * 1e9)
         chunk = frames if args.chunk_frames is None else min(args.chunk_frames, frames)
         while chunk > 64 and chunk * dec_bytes_per_frame > budget:
             chunk = (chunk + 1) // 2
         assert frames % chunk == 0, "frames must be a multiple of the chunk size"
         self.chunk, self.nchunks = chunk, frames // chunk
+        # the fused decode keeps its decisions in LDS: the handle then only needs a token history buffer
         self.dec = HipViterbi(args.code, self.nsteps, nframes=chunk, variant=args.variant, stream=self.stream.cuda_stream,
                               pipeline_depth=self.depth)
         self.dec.enable_timing(True)
@@ -172,6 +174,9 @@ class HipShard:
         sc, oc = self.chunk * self.nsteps * self.spec.R, self.chunk * self.payload_bytes
         out = self.d_out[i % len(self.d_out)]
         for c in range(self.nchunks):
+            if self.windowed:
+                self.dec.decode_windowed(self.d_syms[c * sc:(c + 1) * sc], self.payload_bits, out[c * oc:(c + 1) * oc])
+                continue
             self.dec.reset()
             self.dec.update(self.d_syms[c * sc:(c + 1) * sc], nbits=self.nsteps)
             self.dec.chainback(self.cb_bits, out=out[c * oc:(c + 1) * oc])
@@ -195,7 +200,7 @@ class HipShard:
         alone_u = alone_c = 0.0
         nalone = 3
         sc_, oc_ = self.chunk * self.nsteps * self.spec.R, self.chunk * self.payload_bytes
-        for _ in range(nalone):
+        for _ in range(0 if self.windowed else nalone):
             for c in range(self.nchunks):
                 self.dec.reset()
                 self.dec.sync()
@@ -204,7 +209,7 @@ class HipShard:
                 self.dec.chainback(self.cb_bits, out=self.d_out[0][c * oc_:(c + 1) * oc_])
                 self.dec.sync()
         au, _, ac, _ = self.dec.read_timing()
-        alone_u, alone_c = au / nalone, ac / nalone
+        alone_u, alone_c = (su / passes, 0.0) if self.windowed else (au / nalone, ac / nalone)
         return {
             "units_per_pass": self.frames * self.nsteps * self.spec.R,
             "bit_errors": nerr,
@@ -252,6 +257,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline-depth", type=int, default=2, help="decision-history buffers behind the handle (K<=15): 2 = double-buffered (default), 1 = strictly serial")
     ap.add_argument("--no-pipeline", action="store_true", help="same as --pipeline-depth 1")
+    ap.add_argument("--windowed", action="store_true", help="K<=9: time the fused sliding-window decode (one kernel, no decision history in HBM) "
+                                                            "instead of init + update + chainback; results are NOT those of the reference chainback")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
     if args.no_pipeline:
@@ -312,7 +319,7 @@ def main():
                     "issue_ceiling_ginstr_per_s": round(vv["issue_ceiling_ginstr_per_s"], 2),
                     "frac": round(rate / vv["issue_ceiling_ginstr_per_s"], 4), "source": vsrc}
         out = {
-            "metric": f"Msymbols/s decoded, K={spec.K} r=1/{spec.R} (init + ACS update + chainback)",
+            "metric": f"Msymbols/s decoded, K={spec.K} r=1/{spec.R} " + ("(fused sliding-window decode: NOT the reference chainback semantics)" if shard.windowed else "(init + ACS update + chainback)"),
             "value": round(core["value"] / 1e6, 6),
             "unit": "Msymbols/s",
             "n_gpus": n_gpus,
@@ -330,7 +337,7 @@ def main():
                        "pipeline_depth": shard.depth,
                        "parallelism": f"frame-shard x{n_gpus}, no collective"},
             "update_msym_s": round(frames * nsteps * spec.R * n_gpus / (upd_ms * 1e-3) / 1e6, 6),
-            "chainback_mbit_s": round(frames * shard.cb_bits * n_gpus / (cb_ms * 1e-3) / 1e6, 3),
+            "chainback_mbit_s": round(frames * shard.cb_bits * n_gpus / (cb_ms * 1e-3) / 1e6, 3) if cb_ms > 0 else None,
             "update_ms": round(upd_ms, 4),
             "chainback_ms": round(cb_ms, 4),
             "kernel_timing": "HIP events recorded by the library around its launches, on the streams they run on, timed region only"

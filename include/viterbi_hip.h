@@ -94,6 +94,20 @@ int vhip_join(vhip_decoder *p);
 int vhip_enable_timing(vhip_decoder *p, int on);
 int vhip_read_timing(vhip_decoder *p, double *update_ms_sum, int *n_update, double *chainback_ms_sum, int *n_chainback);
 
+/* Fused sliding-window decode (additive): init + ACS update + traceback in ONE kernel for the K <= 9
+ * codes with the harness polynomials.  The decisions of the last 64 trellis steps live in an LDS ring; as soon as the row
+ * vhip_window_depth() steps beyond a block of vhip_window_block() payload bits exists, the block is traced back out of the
+ * ring (start state 0) and its bytes are stored -- no decision history and no path metrics ever reach HBM, so the handle's
+ * history buffer is not used and the batch size is not bounded by it.  d_syms: nframes frames of (nbits + K - 1) * R
+ * symbols from a freshly initialised decoder (start state 0); d_data: ceil(nbits/8) bytes per frame, MSB-first.
+ * Results are those of a sliding-window Viterbi decoder -- NOT bit-identical to init/update/chainback unless the depth
+ * covers the frame (the error rate converges on the exact path's as the depth grows: tests/test_windowed.py).  There is no
+ * reference function with these semantics (the reference's decoders that take a traceback length live in its un-vendored
+ * submodule, src/main.cpp:169); they are defined by oracle/viterbi_oracle.c vo_chainback_windowed. */
+int vhip_decode_windowed_dev(vhip_decoder *p, const unsigned char *d_syms, unsigned int nbits, unsigned char *d_data);
+int vhip_window_depth(const vhip_decoder *p); /* traceback depth in trellis steps, or -1 if the code has no fused decode */
+int vhip_window_block(const vhip_decoder *p); /* payload bits decoded per traceback */
+
 /* Stream / device plumbing.  `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
  * NULL selects the device's default stream. */
 int vhip_set_stream(vhip_decoder *p, void *stream);

@@ -51,6 +51,9 @@ SYMBOLS = [
     ("vhip_sync", C.c_int, [C.c_void_p]),
     ("vhip_device_count", C.c_int, []),
     ("vhip_last_error", C.c_char_p, []),
+    ("vhip_decode_windowed_dev", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]),
+    ("vhip_window_depth", C.c_int, [C.c_void_p]),
+    ("vhip_window_block", C.c_int, [C.c_void_p]),
     ("vhip_status", C.c_int, [C.c_void_p]),
     ("vhip_enable_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("vhip_read_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]),

@@ -384,10 +384,35 @@ __device__ __forceinline__ void load_period_fast(const unsigned char *sp, long o
     for (int w = 0; w < SW; w++) d[w] = p[w];
 }
 
+// Where the decision words of a row go: the [group][row][word][lane] history in HBM (the exact path) ...
+template <int DW, int WBYTES>
+struct GlobalSink {
+    unsigned char *dp;  // this lane's slot of the current row
+    __device__ __forceinline__ void put(int w, unsigned word) {
+        // written once, read by the chainback much later: non-temporal stores keep the history from lingering
+        // dirty in L2 / the Infinity Cache (chainback right after the update: 0.219 -> 0.194 ms for K=7)
+        if constexpr (WBYTES == 4) __builtin_nontemporal_store(word, reinterpret_cast<unsigned *>(dp) + w * 64);
+        else __builtin_nontemporal_store((unsigned short)word, reinterpret_cast<unsigned short *>(dp) + w * 64);
+    }
+    __device__ __forceinline__ void next_row(int) { dp += (long)DW * 64 * WBYTES; }
+};
+// ... or a wave-private ring of the last RING rows in LDS, same [row][word][lane] order (the fused windowed decode)
+template <int DW, int WBYTES, int RING>
+struct RingSink {
+    unsigned char *base;  // this lane's slot of ring row 0
+    int slot;             // row & (RING - 1) of the row being written
+    __device__ __forceinline__ void put(int w, unsigned word) {
+        unsigned char *q = base + ((long)slot * DW + w) * 64 * WBYTES;
+        if constexpr (WBYTES == 4) *reinterpret_cast<unsigned *>(q) = word;
+        else *reinterpret_cast<unsigned short *>(q) = (unsigned short)word;
+    }
+    __device__ __forceinline__ void next_row(int) { slot = (slot + 1) & (RING - 1); }
+};
+
 // one period = NB consecutive trellis steps at phases 0..NB-1; GUARD: skip steps outside [row0,row_end)
-template <class C, class P, int LB, bool GUARD, int NR_, int SW_>
+template <class C, class P, int LB, bool GUARD, class Sink, int NR_, int SW_>
 __device__ __forceinline__ void run_period(u16x2 (&M)[NR_], const unsigned (&cur)[SW_], int rbase, int row0, int row_end,
-                                           unsigned lam, unsigned char *&dp) {
+                                           unsigned lam, Sink &sink) {
     using G = RegsCfg<C, P, LB>;
     using S = RegsStep<C, P, LB>;
     constexpr int R = G::R, DW = G::DW;
@@ -404,13 +429,8 @@ __device__ __forceinline__ void run_period(u16x2 (&M)[NR_], const unsigned (&cur
             unsigned words[DW];
             S::template run<PHI>(M, sraw, lam, words);
 #pragma unroll
-            for (int w = 0; w < DW; w++) {
-                // written once, read by the chainback much later: non-temporal stores keep the history from lingering
-                // dirty in L2 / the Infinity Cache (chainback right after the update: 0.219 -> 0.194 ms for K=7)
-                if constexpr (G::WBYTES == 4) __builtin_nontemporal_store(words[w], reinterpret_cast<unsigned *>(dp) + w * 64);
-                else __builtin_nontemporal_store((unsigned short)words[w], reinterpret_cast<unsigned short *>(dp) + w * 64);
-            }
-            dp += (long)DW * 64 * G::WBYTES;
+            for (int w = 0; w < DW; w++) sink.put(w, words[w]);
+            sink.next_row(r);
         }
     });
 }
@@ -449,7 +469,7 @@ __device__ __forceinline__ void acs_regs_body(const AcsRegsArgs &a) {
     const unsigned char *sp = a.syms + fc * (long)a.sym_stride;
     const long lim = (long)a.nsteps * R;
     const bool aligned = ((reinterpret_cast<uintptr_t>(a.syms) | a.sym_stride) & 3) == 0 && ((phi0 * R) & 3) == 0;
-    unsigned char *dp = a.dec + ((wave * a.cap_rows + row0) * (long)DW * 64 + lane) * G::WBYTES;
+    GlobalSink<DW, G::WBYTES> sink{a.dec + ((wave * a.cap_rows + row0) * (long)DW * 64 + lane) * G::WBYTES};
 
     int rbase = row0 - phi0;
     while (rbase < row_end) {
@@ -458,7 +478,7 @@ __device__ __forceinline__ void acs_regs_body(const AcsRegsArgs &a) {
             // slow period: partial head / tail, or unaligned symbols
             unsigned cur[SW];
             load_period_guarded<SW>(sp, (long)(rbase - row0) * R, lim, cur);
-            run_period<C, P, LB, true>(M, cur, rbase, row0, row_end, lam, dp);
+            run_period<C, P, LB, true>(M, cur, rbase, row0, row_end, lam, sink);
             rbase += NB;
             continue;
         }
@@ -476,7 +496,7 @@ __device__ __forceinline__ void acs_regs_body(const AcsRegsArgs &a) {
         for (int i = 0; i < nfull; i++) {
             const long noff = off + NB * R < last_off ? off + NB * R : last_off;  // clamped: no branch around the load
             load_period_fast<SW>(sp, noff, nxt);
-            run_period<C, P, LB, false>(M, cur, rbase, row0, row_end, lam, dp);
+            run_period<C, P, LB, false>(M, cur, rbase, row0, row_end, lam, sink);
 #pragma unroll
             for (int w = 0; w < SW; w++) cur[w] = nxt[w];
             off += NB * R;
@@ -519,6 +539,135 @@ static hipError_t launch_regs(const AcsRegsArgs &a, hipStream_t stream) {
     else
         hipLaunchKernelGGL((acs_regs_kernel<C, P, LB>), dim3((waves + 3) / 4), dim3(256), 0, stream, a);
     return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Fused sliding-window decode: init + ACS update + traceback in ONE kernel.  The trellis steps
+// are those of acs_regs_body, but the decision words go to a wave-private LDS ring of the last RING rows instead of
+// HBM, and whenever the row `DEPTH` steps beyond a block of BLOCK payload bits has been written that block is traced
+// back out of the ring -- start state 0, the walk of chainback_viterbi27_sse2 (viterbi27_sse2.cpp:97-103) over the ring
+// rows -- and its bytes are stored.  No decision history and no path metrics ever reach memory.  Semantics (which differ
+// from the whole-frame chainback unless DEPTH >= the frame): oracle/viterbi_oracle.c vo_chainback_windowed.
+struct DecodeWindowedArgs {
+    const unsigned char *syms;
+    size_t sym_stride;
+    int nsteps;   // trellis steps per frame = nbits + K - 1
+    int nframes;
+    unsigned char *data;
+    size_t data_stride;
+    unsigned nbits;
+};
+
+template <class C, class P, int LB, int DEPTH, int BLOCK>
+__global__ __launch_bounds__(256) void decode_windowed_kernel(DecodeWindowedArgs a) {
+    using G = RegsCfg<C, P, LB>;
+    constexpr int NB = G::NB, R = G::R, NR = G::NR, L = G::L, FPW = G::FPW, DW = G::DW, SW = G::SW, WB = G::WBYTES, NRW = G::NRW;
+    constexpr int RING = 64;
+    static_assert(DEPTH + BLOCK + NB <= RING && BLOCK % 8 == 0 && BLOCK <= 32, "ring too small for this window");
+    constexpr int ROWB = DW * 64 * WB;  // bytes of one ring row of one wave
+    static_assert(4 * RING * ROWB <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char ring_all[4 * RING * ROWB];
+    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const unsigned lam = lane & (L - 1);
+    unsigned char *ring = ring_all + (long)wv * RING * ROWB;
+    const long wave = (long)blockIdx.x * 4 + wv;
+    if (wave * FPW >= a.nframes) return;
+    const long f = wave * FPW + (lane >> LB);
+    const bool fvalid = f < a.nframes;
+    const long fc = fvalid ? f : (long)a.nframes - 1;
+    const int T = a.nsteps;
+
+    // init_viterbi27_sse2 (viterbi27_sse2.cpp:46-52): every state init_all, state 0 (= position 0 at phase 0) init_start
+    u16x2 M[NR];
+#pragma unroll
+    for (int r0 = 0; r0 < NR; r0++) M[r0] = as_v(field_from<G::SAT>(C::init_all) * 0x10001u);
+    if (lam == 0) M[0] = as_v(field_from<G::SAT>(C::init_start) | (field_from<G::SAT>(C::init_all) << 16));
+
+    const unsigned char *sp = a.syms + fc * (long)a.sym_stride;
+    const long lim = (long)T * R;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(a.syms) | a.sym_stride) & 3) == 0;
+    RingSink<DW, WB, RING> sink{ring + lane * WB, 0};
+    unsigned char *out = a.data + fc * (long)a.data_stride;
+    const unsigned nblocks = (a.nbits + BLOCK - 1) / BLOCK;
+    unsigned nextb = 0;
+
+    // one block: payload bits [lo, hi), walked from row top-1 (state 0) down to row lo+NB out of the ring
+    auto emit = [&](unsigned b) {
+        const unsigned lo = b * BLOCK, hi = lo + BLOCK < a.nbits ? lo + BLOCK : a.nbits;
+        const int top = (int)hi + NB + DEPTH < T ? (int)hi + NB + DEPTH : T;
+        unsigned st = 0, v = 0;
+        int rot = top % NB;  // (r + 1) mod NB at the first row visited, r = top - 1
+        const unsigned lane0 = lane & ~(unsigned)(L - 1);  // first lane of this frame's lane group
+        for (int r = top - 1; r >= (int)lo + NB; r--) {
+            const unsigned p = rot == 0 ? st : (((st >> rot) | (st << (NB - rot))) & (G::N - 1));
+            const unsigned lm = p & (L - 1), h = (p >> LB) & 1u, rho = p >> (LB + 1);
+            const unsigned w = rho / NRW, bit = (rho % NRW) + NRW * h;
+            const unsigned char *q = ring + ((long)(r & (RING - 1)) * DW + w) * 64 * WB + (lane0 + lm) * WB;
+            const unsigned word = WB == 4 ? *reinterpret_cast<const unsigned *>(q) : *reinterpret_cast<const unsigned short *>(q);
+            const unsigned k = (word >> bit) & 1u;
+            st = (st >> 1) | (k << (NB - 1));
+            const int i = r - NB;
+            if (i < (int)hi) v |= k << (31 - (i - (int)lo));  // MSB-first inside the block
+            rot = rot == 0 ? NB - 1 : rot - 1;
+        }
+        if (fvalid && lam == 0) {
+            const unsigned nbytes = (hi - lo + 7) / 8;
+#pragma unroll
+            for (unsigned m = 0; m < BLOCK / 8; m++)
+                if (m < nbytes) out[lo / 8 + m] = (unsigned char)(v >> (24 - 8 * m));
+        }
+    };
+    auto emit_ready = [&](int rows_done) {
+        while (nextb < nblocks) {
+            const unsigned hi = (nextb + 1) * BLOCK < a.nbits ? (nextb + 1) * BLOCK : a.nbits;
+            const int top = (int)hi + NB + DEPTH < T ? (int)hi + NB + DEPTH : T;
+            if (top > rows_done) break;
+            emit(nextb++);
+        }
+    };
+
+    int rbase = 0;
+    while (rbase < T) {
+        const bool full = rbase + NB <= T;
+        unsigned cur[SW];
+        if (aligned && full) load_period_fast<SW>(sp, (long)rbase * R, cur);
+        else load_period_guarded<SW>(sp, (long)rbase * R, lim, cur);
+        if (full) run_period<C, P, LB, false>(M, cur, rbase, 0, T, lam, sink);
+        else run_period<C, P, LB, true>(M, cur, rbase, 0, T, lam, sink);
+        rbase += NB;
+        emit_ready(rbase < T ? rbase : T);
+    }
+}
+
+template <class C, class P, int LB, int DEPTH, int BLOCK>
+static hipError_t launch_windowed(const DecodeWindowedArgs &a, hipStream_t stream) {
+    using G = RegsCfg<C, P, LB>;
+    const int waves = (a.nframes + G::FPW - 1) / G::FPW;
+    hipLaunchKernelGGL((decode_windowed_kernel<C, P, LB, DEPTH, BLOCK>), dim3((waves + 3) / 4), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// K=7: one lane per frame (512-byte ring rows), depth 48, blocks of 8 bits; K=9: four lanes per frame (the only geometry
+// whose ring fits the LDS), depth 40, blocks of 16 bits
+void windowed_params(int code, int *depth, int *block, int *lb) {
+    const bool k7 = code_info(code).K == 7;
+    *depth = k7 ? 48 : 40;
+    *block = k7 ? 8 : 16;
+    *lb = k7 ? 0 : 2;
+}
+
+hipError_t launch_decode_windowed(int code, const unsigned char *syms, size_t sym_stride, int nsteps, int nframes, unsigned char *data,
+                                  size_t data_stride, unsigned nbits, hipStream_t stream) {
+    const DecodeWindowedArgs a{syms, sym_stride, nsteps, nframes, data, data_stride, nbits};
+    switch (code) {
+    case VHIP_KA9Q27: return launch_windowed<Code27, Poly27, 0, 48, 8>(a, stream);
+    case VHIP_SPIRAL47: return launch_windowed<Code47, Poly47, 0, 48, 8>(a, stream);
+    case VHIP_SPIRAL27: return launch_windowed<CodeS27, Poly27, 0, 48, 8>(a, stream);
+    case VHIP_KA9Q29: return launch_windowed<Code29, Poly29, 2, 40, 16>(a, stream);
+    case VHIP_SPIRAL49: return launch_windowed<Code49, Poly49, 2, 40, 16>(a, stream);
+    case VHIP_SPIRAL29: return launch_windowed<CodeS29, Poly29, 2, 40, 16>(a, stream);
+    }
+    return hipErrorInvalidValue;
 }
 
 bool regs_poly_supported(int code, const int *poly) {

@@ -66,6 +66,10 @@ bool regs_poly_supported(int code, const int *poly);
 bool regs_lanes_supported(int code, int lb);
 RegsLayout regs_layout(int code, int lb);
 hipError_t launch_acs_regs(int code, int lb, const AcsRegsArgs &a, hipStream_t stream);
+// fused sliding-window decode (K <= 9, harness polynomials): depth / block / lanes-per-frame log2 per code
+void windowed_params(int code, int *depth, int *block, int *lb);
+hipError_t launch_decode_windowed(int code, const unsigned char *syms, size_t sym_stride, int nsteps, int nframes, unsigned char *data,
+                                  size_t data_stride, unsigned nbits, hipStream_t stream);
 struct ChainbackRegsArgs {
     const unsigned char *dec;
     RegsLayout lay;

@@ -790,6 +790,39 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
     return 0;
 }
 
+// ---------------------------------------------------------------- fused sliding-window decode
+int vhip_window_depth(const vhip_decoder *p) {
+    if (!p || p->K > 9 || !vh::regs_poly_supported(p->code, p->poly)) return -1;
+    int d, b, lb;
+    vh::windowed_params(p->code, &d, &b, &lb);
+    return d;
+}
+int vhip_window_block(const vhip_decoder *p) {
+    if (!p || p->K > 9 || !vh::regs_poly_supported(p->code, p->poly)) return -1;
+    int d, b, lb;
+    vh::windowed_params(p->code, &d, &b, &lb);
+    return b;
+}
+
+int vhip_decode_windowed_dev(vhip_decoder *p, const unsigned char *d_syms, unsigned int nbits, unsigned char *d_data) {
+    StatusScope status_scope(p);
+    if (!p) return fail("decode_windowed: NULL handle");
+    if (use_device(p) != 0) return -1;
+    if (vhip_window_depth(p) < 0) return fail("decode_windowed: built for K <= 9 with the harness polynomials");
+    if (nbits == 0) return 0;
+    const int steps = (int)nbits + p->K - 1;
+    if (steps > p->cap_rows) return fail("decode_windowed: more trellis steps than the handle was created for");
+    if (order_behind_caller(p) != 0) return -1;
+    struct TimeScope {
+        hipEvent_t e1;
+        hipStream_t st;
+        ~TimeScope() { timing_end(e1, st); }
+    } time_scope{timing_begin(p, p->t_upd, p->run_stream()), p->run_stream()};
+    const int steps_run = p->incremental ? steps : (steps / 2) * 2;  // update_spiral47 drops an odd last step (spiral47.cpp:536-538)
+    HIP_TRY(vh::launch_decode_windowed(p->code, d_syms, (size_t)steps * p->R, steps_run, p->nframes, d_data, (nbits + 7) / 8, nbits, p->run_stream()));
+    return 0;
+}
+
 int vhip_update(vhip_decoder *p, const unsigned char *syms, int nbits) {
     StatusScope status_scope(p);
     if (!p) return fail("update: NULL handle");

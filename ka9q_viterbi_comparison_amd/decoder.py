@@ -132,6 +132,21 @@ class HipViterbi:
             raise _lib.VhipError(f"vhip_chainback failed: {_lib.last_error()}")
         return data, rc
 
+    # -- fused sliding-window decode (no decision history in HBM) ------------------------------------------
+    @property
+    def window(self):
+        """(traceback depth, block bits) of decode_windowed, or None when the code has no fused decode."""
+        d = self._lib.vhip_window_depth(self._h)
+        return (d, self._lib.vhip_window_block(self._h)) if d >= 0 else None
+
+    def decode_windowed(self, symbols, total_bits, out):
+        """symbols / out: torch cuda uint8 tensors (nframes x (total_bits+K-1)*R symbols in, nframes x ceil(total_bits/8) bytes out)."""
+        assert symbols.is_cuda and symbols.is_contiguous() and out.is_cuda and out.is_contiguous()
+        assert symbols.numel() >= self.nframes * (total_bits + self.K - 1) * self.R and out.numel() >= self.nframes * ((total_bits + 7) // 8)
+        _lib.check(self._lib.vhip_decode_windowed_dev(self._h, C.c_void_p(symbols.data_ptr()), total_bits, C.c_void_p(out.data_ptr())),
+                   "vhip_decode_windowed_dev")
+        return out
+
     # -- introspection for parity tests --------------------------------------------------------------
     def decision_rows(self, frame, row0, nrows):
         n = 1 << (self.K - 1)

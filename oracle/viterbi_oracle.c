@@ -316,6 +316,38 @@ int vo_chainback(vo_decoder *p, unsigned char *data, unsigned int nbits, unsigne
     return ret;
 }
 
+/* Sliding-window traceback over the rows the update produced.  NOT a reference function: the
+ * ka9q / spiral decoders only have the whole-frame chainback above, and the library whose decoders take a traceback
+ * length (williamyang98/ViterbiDecoderCpp, core->set_traceback_length, src/main.cpp:169) is an un-vendored submodule --
+ * PARITY UNPINNED.  The semantics are defined here and the fused GPU decode (vhip_decode_windowed_dev) is tested against
+ * them bit for bit; with depth >= the frame length they reduce to vo_chainback(nbits, endstate 0).
+ *
+ * Payload bit i is the decision read at row i+K-1 (the generic walk above).  The payload is cut into blocks of `block`
+ * bits; block b = bits [lo, hi) is decoded by a walk that starts in state 0 at row min(hi+K-1+depth, rows)-1 -- `depth`
+ * steps ahead of the block, where the survivors have merged with high probability, or at the frame's last row, where
+ * the tail forces state 0 -- and keeps the decisions of the rows [lo+K-1, hi+K-1).  Bits are packed MSB-first; the unused
+ * low bits of a last partial byte are 0. */
+int vo_chainback_windowed(vo_decoder *p, unsigned char *data, unsigned int nbits, unsigned int depth, unsigned int block) {
+    if (!p || block == 0 || p->f.chain != CB_GENERIC) return -1;
+    const int K = p->f.K;
+    memset(data, 0, (nbits + 7) / 8);
+    for (unsigned lo = 0; lo < nbits; lo += block) {
+        const unsigned hi = lo + block < nbits ? lo + block : nbits;
+        long top = (long)hi + (K - 1) + (long)depth;
+        if (top > p->pos) top = p->pos;
+        if (top < (long)hi + (K - 1)) top = (long)hi + (K - 1); /* rows never written read as 0, as in vo_chainback */
+        unsigned st = 0;
+        for (long r = top - 1; r >= (long)lo + (K - 1); r--) {
+            unsigned k = 0;
+            if (r < p->pos) k = (p->rows[(size_t)r * p->row_bytes + (st >> 3)] >> (st & 7u)) & 1u;
+            st = (st >> 1) | (k << (K - 2));
+            const long i = r - (K - 1);
+            if (i < (long)hi && k) data[i >> 3] |= (unsigned char)(0x80u >> (i & 7));
+        }
+    }
+    return 0;
+}
+
 const unsigned char *vo_decision_rows(const vo_decoder *p) { return p->rows; }
 size_t vo_row_bytes(const vo_decoder *p) { return p->row_bytes; }
 int vo_rows_written(const vo_decoder *p) { return p->pos; }

@@ -51,6 +51,10 @@ void vo_update_blk(vo_decoder *p, const unsigned char *syms, int nbits);
 int vo_chainback(vo_decoder *p, unsigned char *data, unsigned int nbits, unsigned int endstate);
 void vo_delete(vo_decoder *p);
 
+/* Sliding-window traceback over the rows written so far (row n4 of SURVEY.md §8f; semantics defined in the .c file --
+ * there is no reference function for it: parity unpinned). */
+int vo_chainback_windowed(vo_decoder *p, unsigned char *data, unsigned int nbits, unsigned int depth, unsigned int block);
+
 /* Introspection for parity tests: decision bitmap rows (little-endian, bit n = new state n, row
  * stride = 2^(K-1)/8 bytes), number of rows written, and the current ("old") path metrics widened to
  * int32 in natural units (u8 value or i16 value). */

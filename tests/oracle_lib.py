@@ -26,6 +26,7 @@ def oracle():
         lib.vo_update_blk.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         lib.vo_update_blk.restype = None
         lib.vo_chainback.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint]
+        lib.vo_chainback_windowed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint]
         lib.vo_delete.argtypes = [C.c_void_p]
         lib.vo_delete.restype = None
         lib.vo_decision_rows.restype = C.c_void_p
@@ -101,6 +102,12 @@ class OracleDecoder:
         data = np.zeros((nbits + 7) // 8, dtype=np.uint8)
         rc = self.lib.vo_chainback(self.h, data.ctypes.data_as(C.c_void_p), nbits, endstate)
         return data, rc
+
+    def chainback_windowed(self, nbits, depth, block):
+        data = np.zeros((nbits + 7) // 8, dtype=np.uint8)
+        rc = self.lib.vo_chainback_windowed(self.h, data.ctypes.data_as(C.c_void_p), nbits, depth, block)
+        assert rc == 0
+        return data
 
     def rows(self, nrows=None):
         n = self.lib.vo_rows_written(self.h) if nrows is None else nrows

@@ -1,0 +1,120 @@
+"""Fused sliding-window decode (vhip_decode_windowed_dev): init + update + traceback in one kernel,
+decisions in an LDS ring, nothing in HBM.  The windowed semantics are not the reference's whole-frame chainback and no
+reference function has them (parity unpinned, see oracle/viterbi_oracle.c vo_chainback_windowed): the GPU is held bit for
+bit to that oracle definition, the oracle definition is tied to the exact path where the two must agree, and the error
+rate is compared with the exact path's."""
+import numpy as np
+import pytest
+
+from common import bit_errors, frames, spec_of
+from ka9q_viterbi_comparison_amd import codes as C
+from oracle_lib import OracleDecoder
+
+WINDOWED = ["27", "47", "spiral27", "29", "49", "spiral29"]
+
+
+@pytest.mark.parametrize("name", WINDOWED)
+def test_oracle_windowed_reduces_to_exact_chainback(name):
+    """depth >= frame length: every block is walked from the frame's last row in state 0 = the reference chainback with
+    endstate 0 (viterbi27_sse2.cpp:78-105), whatever the block size; ragged bit counts included."""
+    spec = C.CODES[name]
+    for B, nbits in ((24, 24 * 8), (24, 24 * 8 - 5), (3, 17)):
+        steps = nbits + spec.K - 1
+        steps -= 0 if spec.family == "ka9q-u8-mod" else steps % 2
+        _, syms = frames(spec.code, 5, 2, B, spec.ebn0_db)
+        for f in range(2):
+            o = OracleDecoder(spec.code, spec.poly, steps)
+            o.update(syms[f][:steps * spec.R], steps)
+            exact, _ = o.chainback(nbits)
+            for block in (8, 16, 32):
+                assert np.array_equal(o.chainback_windowed(nbits, steps, block), exact), (B, nbits, block)
+            o.close()
+
+
+def test_oracle_windowed_error_rate_converges_with_depth():
+    """K=7 at 3 dB: the fixed start state costs errors at small depth and nothing at depth 48 (what the GPU kernel uses)."""
+    spec = C.CODES["27"]
+    B, nframes = 128, 24
+    steps = B * 8 + spec.K - 1
+    payload, syms = frames(spec.code, 11, nframes, B, spec.ebn0_db - 1.0)
+    errs = {d: 0 for d in (16, 32, 48)}
+    exact = 0
+    for f in range(nframes):
+        o = OracleDecoder(spec.code, spec.poly, steps)
+        o.update(syms[f], steps)
+        exact += bit_errors(o.chainback(B * 8)[0], payload[f])
+        for d in errs:
+            errs[d] += bit_errors(o.chainback_windowed(B * 8, d, 8), payload[f])
+        o.close()
+    assert errs[16] > errs[32] >= errs[48] and errs[48] <= exact + 5 + exact // 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", WINDOWED)
+@pytest.mark.parametrize("mode", ["hard", "awgn", "noisy"])
+def test_fused_decode_matches_windowed_oracle(name, mode):
+    """The GPU's fused decode == the oracle's sliding-window traceback over the oracle's decision rows, byte for byte, with
+    the depth / block the library reports: more than one wave of frames, a ragged frame count, payload sizes that are not a
+    multiple of the block, frames shorter than the window, odd step counts (the spiral decoders drop an odd last step,
+    spiral47.cpp:536-538, in the fused decode as in update_spiral47)."""
+    import torch
+
+    from ka9q_viterbi_comparison_amd import HipViterbi
+
+    spec = C.CODES[name]
+    ebn0 = {"hard": None, "awgn": spec.ebn0_db, "noisy": spec.ebn0_db - 3.0}[mode]
+    for B, nbits, nframes in ((60, 480, 70), (23, 23 * 8 - 3, 17), (2, 13, 5)):
+        steps = nbits + spec.K - 1
+        payload, syms = frames(spec.code, 40 + B, nframes, B, ebn0)
+        syms = np.ascontiguousarray(syms[:, :steps * spec.R])
+        dec = HipViterbi(name, steps, nframes=nframes, stream=torch.cuda.current_stream().cuda_stream)
+        depth, block = dec.window
+        out = torch.full((nframes * ((nbits + 7) // 8),), 0xEE, dtype=torch.uint8, device="cuda")
+        dec.decode_windowed(torch.from_numpy(syms).cuda(), nbits, out)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().reshape(nframes, (nbits + 7) // 8)
+        for f in range(nframes):
+            o = OracleDecoder(spec.code, spec.poly, steps)
+            o.update(syms[f], steps)
+            ref = o.chainback_windowed(nbits, depth, block)
+            assert np.array_equal(got[f], ref), (name, mode, B, nbits, f)
+            if mode == "hard" and nbits == B * 8:  # a whole frame: the tail forces state 0 at the last row
+                assert bit_errors(got[f], payload[f]) == 0
+            o.close()
+        dec.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,frames_", [("27", 65536), ("49", 8192)])
+def test_fused_decode_full_batch_error_rate_and_no_history(name, frames_):
+    """Config-2 sized batch through the fused decode: noise-free input decodes without error and the AWGN error count is
+    close to the exact path's (init / update / chainback on the same handle and symbols)."""
+    import torch
+
+    from ka9q_viterbi_comparison_amd import HipViterbi, count_bit_errors_dev, gen_frames_dev, noise_q12
+
+    spec = C.CODES[name]
+    bits = 2048
+    B, steps = bits // 8, bits + spec.K - 1
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    d_payload = torch.empty(frames_ * B, dtype=torch.uint8, device=dev)
+    d_syms = torch.empty(frames_ * steps * spec.R, dtype=torch.uint8, device=dev)
+    d_win = torch.zeros(frames_ * B, dtype=torch.uint8, device=dev)
+    d_exact = torch.zeros(frames_ * B, dtype=torch.uint8, device=dev)
+    dec = HipViterbi(name, steps, nframes=frames_, stream=stream)
+    gen_frames_dev(spec, 3, 0, frames_, B, C.HARD_AMP_Q16, 0, d_payload, d_syms, stream)
+    dec.decode_windowed(d_syms, bits, d_win)
+    assert count_bit_errors_dev(d_win, d_payload, frames_ * B, stream) == 0
+    gen_frames_dev(spec, 3, 0, frames_, B, C.SOFT_AMP_Q16, noise_q12(spec.R, C.SOFT_AMP, spec.ebn0_db), d_payload, d_syms, stream)
+    dec.decode_windowed(d_syms, bits, d_win)
+    dec.reset()
+    dec.update(d_syms, nbits=steps)
+    dec.chainback(bits, out=d_exact)
+    e_win = count_bit_errors_dev(d_win, d_payload, frames_ * B, stream)
+    e_exact = count_bit_errors_dev(d_exact, d_payload, frames_ * B, stream)
+    assert e_exact > 0
+    # K=7 at depth 48: indistinguishable from the exact path; K=9 at depth 40 (what fits the LDS ring): a measurable penalty
+    limit = 1.1 if spec.K == 7 else 4.0
+    assert e_exact * 0.8 <= e_win <= e_exact * limit + 50, (e_win, e_exact)
+    dec.close()

@@ -11,7 +11,8 @@
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
-P=$R/profiles
+P=$O/profiles   # gpurun merges only gpurun_out/ back: copy $P/* into profiles/ afterwards
+export PROFILES_DIR=$P
 mkdir -p $O $P
 cd /tmp && export TMPDIR=/tmp
 prof() { # name, code, extra bench args...
@@ -53,6 +54,10 @@ for c in 27 47 29 49; do python3 bench.py --code $c --frames 131072 --steps 5 --
 python3 bench.py --code 615 --frames 131072 --steps 2 --warmup 1 --no-cpu-baseline 2>> $O/shard.err | tail -n 1 >> $P/${TAG}_config5_shard_size.jsonl
 python3 bench.py --code 224 --frames 12 --payload-bits 64 --steps 2 --warmup 1 --no-cpu-baseline 2>> $O/shard.err | tail -n 1 >> $P/${TAG}_config5_shard_size.jsonl
 echo "shard-size lines done"
+: > $P/${TAG}_windowed_decode.jsonl
+for c in 27 47 29 49; do python3 bench.py --code $c --windowed --steps 20 --warmup 3 --no-cpu-baseline 2>> $O/shard.err | tail -n 1 >> $P/${TAG}_windowed_decode.jsonl; done
+python3 bench.py --code 27 --windowed --frames 1048576 --steps 3 --warmup 1 --no-cpu-baseline 2>> $O/shard.err | tail -n 1 >> $P/${TAG}_windowed_decode.jsonl
+echo "windowed lines done"
 ./harness/viterbi_bench -t 1.0 -n 8 -o $P/${TAG}_harness_default.json > $O/harness.log 2>&1
 ./harness/viterbi_bench -t 1.0 -n 8 --host-api --hard -o $P/${TAG}_harness_host_1frame.json >> $O/harness.log 2>&1
 python3 tools/tabulate_results.py $P/${TAG}_harness_default.json $P/${TAG}_harness_host_1frame.json > $P/${TAG}_harness_tables.md 2>> $O/harness.log

@@ -51,7 +51,7 @@ def main():
         "note": "separate --pmc passes; FETCH_SIZE x2 (gfx950 half-count of wide reads), WRITE_SIZE exact; KiB -> bytes",
     }
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "profiles", f"traffic_{code}.json")
+    path = os.path.join(os.environ.get("PROFILES_DIR", os.path.join(root, "profiles")), f"traffic_{code}.json")
     json.dump(out, open(path, "w"), indent=1)
     print(path, out)
 

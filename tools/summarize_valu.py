@@ -34,7 +34,7 @@ def main():
            "note": "ceiling = 1024 SIMDs x one VOP3P wave64 instruction per 1.8 ns (profiles/r01_valu_rate.txt); "
                    "full-rate VOP2 instructions issue faster, so a mixed stream can exceed 1.0 slightly"}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = os.path.join(root, "profiles", f"valu_{code}.json")
+    p = os.path.join(os.environ.get("PROFILES_DIR", os.path.join(root, "profiles")), f"valu_{code}.json")
     json.dump(out, open(p, "w"), indent=1)
     print(p, json.dumps(out)[:400])
 
