@@ -125,6 +125,12 @@ enum vhip_variant {
     VHIP_VARIANT_HBM_TILED = 5  /* K=24: 9 or 14 steps per pass -- two passes per 23 steps, tiles regrouped through LDS */
 };
 int vhip_set_variant(vhip_decoder *p, int variant);
+/* Polynomials other than the reference harness's (src/main.cpp:367-415): the fast kernels are compiled for them when the
+ * handle is created (hipcc --genco on the library's own kernel sources, a few seconds, cached under $VHIP_JIT_CACHE or
+ * /tmp/vhip_jit_cache_<uid>) and run at the speed of the harness polynomials; 1 = this handle runs such a build.  Without
+ * the sources or hipcc next to the library, or with VHIP_JIT=0, the handle uses the slower any-polynomial kernels
+ * (VHIP_VARIANT_LDS / VHIP_VARIANT_HBM) and asking for the fast variant explicitly is an error. */
+int vhip_is_runtime_specialised(const vhip_decoder *p);
 int vhip_get_variant(const vhip_decoder *p);
 
 /* Introspection for parity tests (blocking): natural decision bitmap rows (bit n of a row = new state n,

@@ -39,7 +39,11 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int K = 15, R = 6, NB = 14, N = 1 << NB;
 constexpr int THREADS = 128, NR = 64;
+#ifdef VH_JIT_KERNEL
+constexpr int POLY[6] = VH_JIT_POLY;  // runtime specialisation (jit.hip): the caller's polynomials
+#else
 constexpr int POLY[6] = {042631, 047245, 056507, 073363, 077267, 064537};  // src/main.cpp:405
+#endif
 
 template <class F, int... Is>
 __device__ __forceinline__ void sfor_impl(F &&f, std::integer_sequence<int, Is...>) {
@@ -257,7 +261,7 @@ struct Smem {
 };
 
 template <bool SP>
-__global__ __launch_bounds__(THREADS, 2) void acs_k15_kernel(AcsK15Args a) {
+__device__ __forceinline__ void acs_k15_body(const AcsK15Args &a) {
     __shared__ Smem sm;
     const SignMasks sgm;
     const unsigned tid = threadIdx.x;
@@ -399,6 +403,12 @@ __global__ __launch_bounds__(THREADS, 2) void acs_k15_kernel(AcsK15Args a) {
     }
 }
 
+template <bool SP>
+__global__ __launch_bounds__(THREADS, 2) void acs_k15_kernel(AcsK15Args a) {
+    acs_k15_body<SP>(a);
+}
+
+#ifndef VH_JIT_KERNEL
 // chainback over the K=15 layout; same walk as chainback_viterbi615_sse2 (viterbi615_sse2.cpp:65-91, 32-bit word
 // semantics -- SURVEY.md §0.3).  One thread per frame; one dependent 4-byte load per decoded bit.
 __global__ __launch_bounds__(64) void chainback_k15_kernel(ChainbackRowsArgs a) {
@@ -426,8 +436,11 @@ __global__ __launch_bounds__(64) void chainback_k15_kernel(ChainbackRowsArgs a) 
     }
 }
 
+#endif  // !VH_JIT_KERNEL
+
 }  // namespace k15
 
+#ifndef VH_JIT_KERNEL
 bool k15_poly_supported(const int *poly) {
     for (int r = 0; r < 6; r++)
         if (poly[r] != k15::POLY[r]) return false;
@@ -445,4 +458,10 @@ hipError_t launch_chainback_k15(const ChainbackRowsArgs &a, hipStream_t stream) 
     return hipGetLastError();
 }
 
+#endif  // !VH_JIT_KERNEL
+
 }  // namespace vh
+
+#ifdef VH_JIT_KERNEL
+extern "C" __global__ __launch_bounds__(128, 2) void vh_jit_acs_k15(vh::AcsK15Args a) { vh::k15::acs_k15_body<VH_JIT_SPIRAL>(a); }
+#endif

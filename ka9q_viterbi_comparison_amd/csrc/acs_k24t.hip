@@ -34,7 +34,11 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int NB = 23;
 constexpr unsigned N = 1u << NB;
+#ifdef VH_JIT_KERNEL
+constexpr int POLY[2] = VH_JIT_POLY;  // runtime specialisation (jit.hip): the caller's polynomials
+#else
 constexpr int POLY[2] = {062650457, 062650455};  // src/main.cpp:415
+#endif
 
 template <class F, int... Is>
 __device__ __forceinline__ void sfor_impl(F &&f, std::integer_sequence<int, Is...>) {
@@ -203,10 +207,9 @@ __device__ __forceinline__ void load_symbols(const unsigned char *syms, int s_lo
 __device__ __forceinline__ unsigned h_row(unsigned row) { return row ^ ((row >> 4) & 1u); }
 
 template <bool FULL, int MODE>
-__global__ __launch_bounds__(512) void acs_k24t_pass_h_kernel(const int16_t *oldm, int16_t *__restrict__ newm,
-                                                              unsigned char *__restrict__ rows, const unsigned char *syms,
-                                                              int rel_row0, int s_lo, int s_hi, int *__restrict__ flags,
-                                                              K24Report mirror) {
+__device__ __forceinline__ void pass_h_body(const int16_t *oldm, int16_t *__restrict__ newm, unsigned char *__restrict__ rows,
+                                            const unsigned char *syms, int rel_row0, int s_lo, int s_hi, int *__restrict__ flags,
+                                            K24Report mirror) {
     // rows/syms point at the row of the pass's first phase; rel_row0 = that row's index in the call
     int pending = flags[K24F_PENDING];  // looked at below, behind the metric loads
     const SignMasks sm;
@@ -259,10 +262,15 @@ __global__ __launch_bounds__(512) void acs_k24t_pass_h_kernel(const int16_t *old
 __device__ __forceinline__ unsigned l_swz(unsigned d) { return d ^ (((d >> 8) & 31u) << 3); }
 
 template <bool FULL, int MODE>
-__global__ __launch_bounds__(256, 2) void acs_k24t_pass_l_kernel(const int16_t *oldm, int16_t *__restrict__ newm,
-                                                                 unsigned char *__restrict__ rows, const unsigned char *syms,
-                                                                 int rel_row0, int s_lo, int s_hi, int *__restrict__ flags,
-                                                                 K24Report mirror) {
+__global__ __launch_bounds__(512) void acs_k24t_pass_h_kernel(const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,
+                                                              int rel_row0, int s_lo, int s_hi, int *flags, K24Report mirror) {
+    pass_h_body<FULL, MODE>(oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);
+}
+
+template <bool FULL, int MODE>
+__device__ __forceinline__ void pass_l_body(const int16_t *oldm, int16_t *__restrict__ newm, unsigned char *__restrict__ rows,
+                                            const unsigned char *syms, int rel_row0, int s_lo, int s_hi, int *__restrict__ flags,
+                                            K24Report mirror) {
     int pending = flags[K24F_PENDING];
     const SignMasks sm;
     __shared__ __attribute__((aligned(16))) unsigned img[8192];
@@ -322,8 +330,15 @@ __global__ __launch_bounds__(256, 2) void acs_k24t_pass_l_kernel(const int16_t *
     }
 }
 
+template <bool FULL, int MODE>
+__global__ __launch_bounds__(256, 2) void acs_k24t_pass_l_kernel(const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,
+                                                                 int rel_row0, int s_lo, int s_hi, int *flags, K24Report mirror) {
+    pass_l_body<FULL, MODE>(oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);
+}
+
 }  // namespace k24t
 
+#ifndef VH_JIT_KERNEL
 bool k24t_poly_supported(const int *poly) { return poly[0] == k24t::POLY[0] && poly[1] == k24t::POLY[1]; }
 
 // one pass: stages [s_lo, s_hi) of pass `pass` (0 = H: phases 0..8, 1 = L: phases 9..22); rows/syms are those of the pass's
@@ -354,4 +369,18 @@ hipError_t launch_k24t_pass(int pass, const int16_t *oldm, int16_t *newm, unsign
     return launch_pass_mode<0>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream);
 }
 
+#endif  // !VH_JIT_KERNEL
+
 }  // namespace vh
+
+#ifdef VH_JIT_KERNEL
+#define VH_JIT_PASS(NAME, BODY, FULL, BOUNDS)                                                                                    \
+    extern "C" __global__ BOUNDS void NAME(const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,  \
+                                           int rel_row0, int s_lo, int s_hi, int *flags, vh::K24Report mirror) {                 \
+        vh::k24t::BODY<FULL, 0>(oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);                                    \
+    }
+VH_JIT_PASS(vh_jit_k24t_h_full, pass_h_body, true, __launch_bounds__(512))
+VH_JIT_PASS(vh_jit_k24t_h_part, pass_h_body, false, __launch_bounds__(512))
+VH_JIT_PASS(vh_jit_k24t_l_full, pass_l_body, true, __launch_bounds__(256, 2))
+VH_JIT_PASS(vh_jit_k24t_l_part, pass_l_body, false, __launch_bounds__(256, 2))
+#endif

@@ -530,6 +530,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     acs_regs_body<C, P, LB>(a);
 }
 
+#ifndef VH_JIT_KERNEL  // everything from here to the end of the namespace is launch code and polynomial-independent kernels
 template <class C, class P, int LB>
 static hipError_t launch_regs(const AcsRegsArgs &a, hipStream_t stream) {
     using G = RegsCfg<C, P, LB>;
@@ -1160,4 +1161,18 @@ hipError_t launch_chainback_regs(const ChainbackRegsArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
+#endif  // !VH_JIT_KERNEL
+
 }  // namespace vh
+
+#ifdef VH_JIT_KERNEL
+// Runtime specialisation (jit.hip): this file is compiled again by hipcc --genco with the caller's polynomials as the
+// compile-time constants the unrolled phases need -- VH_JIT_CODE (a traits type of viterbi_codes.h), VH_JIT_POLY ({a,b,..}),
+// VH_JIT_LB -- and yields exactly one kernel.
+namespace vh {
+struct PolyJit { static constexpr int v[8] = VH_JIT_POLY; };
+}
+extern "C" __global__ __launch_bounds__(256) VH_JIT_ATTR void vh_jit_acs_regs(vh::AcsRegsArgs a) {
+    vh::acs_regs_body<vh::VH_JIT_CODE, vh::PolyJit, VH_JIT_LB>(a);
+}
+#endif

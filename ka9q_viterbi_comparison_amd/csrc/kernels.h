@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <string>
+
 namespace vh {
 
 #if defined(__HIPCC__)
@@ -139,6 +141,11 @@ hipError_t launch_chainback_k24f(const ChainbackRowsArgs &a, bool tiled, hipStre
 bool k24t_poly_supported(const int *poly);
 hipError_t launch_k24t_pass(int pass, const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,
                             int rel_row0, int s_lo, int s_hi, int *flags, K24Report mirror, hipStream_t stream);
+
+// ---------------------------------------------------------------- jit.hip (fast kernels for other polynomials)
+bool jit_enabled();  // VHIP_JIT=0 turns the runtime specialisation off
+bool jit_function(const char *src, const std::string &defs, const char *kname, hipFunction_t *fn, std::string *err);
+std::string jit_poly_define(const int *poly, int n);
 
 // ---------------------------------------------------------------- chainback_spec.hip (K = 15 / 24, one wave per frame)
 enum { CB_LAY_NATURAL = 0, CB_LAY_K15 = 1, CB_LAY_K24F = 2, CB_LAY_K15_SIGN_BYTES = 3, CB_LAY_K24T = 4 };

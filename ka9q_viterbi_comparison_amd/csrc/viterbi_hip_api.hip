@@ -97,6 +97,9 @@ struct vhip_decoder {
     int depth = 1, cur_slot = 0;
     hipEvent_t ev_input = nullptr;     // "the caller's stream has reached this call" (inputs are ready)
     int status = 0;                    // 0, or -1 after a failed call on this handle (vhip_status)
+    // fast kernels compiled at run time for this handle's polynomials (jit.hip): regs / k15: [0]; k24t: H full, H part, L full, L part
+    bool jit = false;
+    hipFunction_t jit_fn[4] = {};
     // live kernel timing (vhip_enable_timing): event pairs around the update / chainback launches, on the stream they run on
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;                        // timing-enabled events, reused
@@ -218,6 +221,40 @@ int auto_variant(const vhip_decoder *p) {
     return VHIP_VARIANT_LDS;
 }
 
+bool fast_poly_supported(const vhip_decoder *p) {
+    if (p->code == VHIP_KA9Q224) return vh::k24t_poly_supported(p->poly);
+    if (p->K == 15) return vh::k15_poly_supported(p->poly);
+    return vh::regs_poly_supported(p->code, p->poly);
+}
+
+// Compile (or fetch from the cache) the fast kernel of this handle's code for ITS polynomials.  lb: lanes-per-frame log2 (K <= 9).
+bool setup_jit(vhip_decoder *p, int lb, std::string *err) {
+    if (!vh::jit_enabled()) {
+        *err = "runtime specialisation is switched off (VHIP_JIT=0)";
+        return false;
+    }
+    const std::string poly = vh::jit_poly_define(p->poly, p->R);
+    if (p->code == VHIP_KA9Q224) {
+        const char *names[4] = {"vh_jit_k24t_h_full", "vh_jit_k24t_h_part", "vh_jit_k24t_l_full", "vh_jit_k24t_l_part"};
+        for (int i = 0; i < 4; i++)
+            if (!vh::jit_function("acs_k24t.hip", poly, names[i], &p->jit_fn[i], err)) return false;
+        return true;
+    }
+    if (p->K == 15)
+        return vh::jit_function("acs_k15.hip", poly + (p->code == VHIP_SPIRAL615 ? " -DVH_JIT_SPIRAL=true" : " -DVH_JIT_SPIRAL=false"), "vh_jit_acs_k15",
+                                &p->jit_fn[0], err);
+    const char *traits = p->code == VHIP_KA9Q27 ? "Code27" : p->code == VHIP_KA9Q29 ? "Code29" : p->code == VHIP_SPIRAL47 ? "Code47"
+                       : p->code == VHIP_SPIRAL49 ? "Code49" : p->code == VHIP_SPIRAL27 ? "CodeS27" : p->code == VHIP_SPIRAL29 ? "CodeS29" : nullptr;
+    if (!traits || !vh::regs_lanes_supported(p->code, lb)) {
+        *err = "no register kernel for this code / lanes per frame";
+        return false;
+    }
+    const int nr = (int)(p->N >> (lb + 1));  // packed registers per lane: >= 32 takes the two-waves-per-SIMD scheduling hint, as launch_regs
+    std::string defs = std::string("-DVH_JIT_CODE=") + traits + " " + poly + " -DVH_JIT_LB=" + std::to_string(lb);
+    defs += nr >= 32 ? " '-DVH_JIT_ATTR=__attribute__((amdgpu_waves_per_eu(1,2)))'" : " -DVH_JIT_ATTR=";
+    return vh::jit_function("acs_regs.hip", defs, "vh_jit_acs_regs", &p->jit_fn[0], err);
+}
+
 void apply_variant(vhip_decoder *p, int variant, int lb) {
     p->variant = variant;
     if (variant == VHIP_VARIANT_REGS && p->K != 15) {
@@ -293,7 +330,19 @@ int k24f_update_frame(vhip_decoder *p, int f, const unsigned char *d_syms, int s
     auto launch = [&](const Pass &q, bool report) -> int {
         const long row_g0 = (long)row0 + q.rel - q.s_lo;  // absolute row of the group's phase 0 (may precede row0)
         const vh::K24Report rep{report ? d_word : nullptr, q.seq};
-        if (tiled)
+        if (tiled && p->jit) {
+            // the run-time build of acs_k24t.hip for this handle's polynomials: same arguments, same grids as launch_k24t_pass
+            const int16_t *oldm = buf[q.in];
+            int16_t *newm = buf[q.in ^ 1];
+            unsigned char *rw = rows + row_g0 * (long)p->row_bytes;
+            const unsigned char *sy = d_syms + ((long)q.rel - q.s_lo) * 2;
+            int rel0 = q.rel - q.s_lo, s_lo = q.s_lo, s_hi = q.s_hi;
+            int *fl = flags;
+            vh::K24Report rp = rep;
+            void *args[] = {&oldm, &newm, &rw, &sy, &rel0, &s_lo, &s_hi, &fl, &rp};
+            const bool full = s_lo == 0 && s_hi == vh::k24t_pass_nphases(q.g);
+            HIP_TRY(hipModuleLaunchKernel(p->jit_fn[q.g * 2 + (full ? 0 : 1)], q.g == 0 ? 256 : 512, 1, 1, q.g == 0 ? 512 : 256, 1, 1, 0, stream, args, nullptr));
+        } else if (tiled)
             HIP_TRY(vh::launch_k24t_pass(q.g, buf[q.in], buf[q.in ^ 1], rows + row_g0 * (long)p->row_bytes,
                                          d_syms + ((long)q.rel - q.s_lo) * 2, q.rel - q.s_lo, q.s_lo, q.s_hi, flags, rep, stream));
         else
@@ -410,6 +459,18 @@ vhip_decoder *vhip_create(int code, const int *poly, int len, int nframes) {
     p->frames_padded = (code == VHIP_KA9Q224) ? nframes : ((nframes + 63) / 64) * 64;
     apply_variant(p, auto_variant(p), auto_regs_lb(code, nframes));
     (void)hipGetDevice(&p->device);
+    if (!fast_poly_supported(p)) {
+        // other polynomials than the harness set: the same fast kernel, compiled for them now (jit.hip); if that is not
+        // possible here (no sources / no hipcc / VHIP_JIT=0) the handle keeps the any-polynomial kernel chosen above
+        const int lb = auto_regs_lb(code, nframes);
+        std::string why;
+        if (setup_jit(p, lb, &why)) {
+            p->jit = true;
+            apply_variant(p, code == VHIP_KA9Q224 ? VHIP_VARIANT_HBM_TILED : VHIP_VARIANT_REGS, lb);
+        } else if (getenv("VHIP_VERBOSE")) {
+            fprintf(stderr, "viterbi_hip: %s -- using the any-polynomial kernels\n", why.c_str());
+        }
+    }
     const size_t dec_bytes = (size_t)p->frames_padded * (size_t)p->cap_rows * p->row_bytes;
     const size_t met_bytes = (size_t)nframes * p->N * sizeof(int16_t) * (code == VHIP_KA9Q224 ? 2 : 1);
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&p->d_dec), dec_bytes ? dec_bytes : 16);
@@ -575,6 +636,16 @@ int vhip_set_variant(vhip_decoder *p, int variant) {
     const int lb_req = (variant >> 8) - 1;
     variant &= 0xff;
     if (variant == VHIP_VARIANT_AUTO) variant = auto_variant(p);
+    const bool wants_fast = (p->code == VHIP_KA9Q224) ? variant == VHIP_VARIANT_HBM_TILED : variant == VHIP_VARIANT_REGS;
+    if (wants_fast && !fast_poly_supported(p) && (p->code == VHIP_KA9Q224 || p->K == 15 || p->K <= 9)) {
+        const int lb = lb_req >= 0 ? lb_req : auto_regs_lb(p->code, p->nframes);
+        std::string why;
+        if (!setup_jit(p, lb, &why)) return fail(("set_variant: these polynomials need a run-time build of the fast kernel: " + why).c_str());
+        p->jit = true;
+        apply_variant(p, variant, lb);
+        return 0;
+    }
+    p->jit = false;
     if (p->code == VHIP_KA9Q224) {
         if (variant != VHIP_VARIANT_HBM && !k24_multistep(variant)) return fail("set_variant: K=24 supports only the HBM variants");
         if (variant == VHIP_VARIANT_HBM_TILED && !vh::k24t_poly_supported(p->poly))
@@ -685,7 +756,12 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
         a.nframes = p->nframes;
         a.dec = p->d_dec;
         a.metrics = p->d_metrics;
-        HIP_TRY(vh::launch_acs_k15(a, p->code == VHIP_SPIRAL615, p->run_stream()));
+        if (p->jit) {
+            void *args[] = {&a};
+            HIP_TRY(hipModuleLaunchKernel(p->jit_fn[0], (unsigned)a.nframes, 1, 1, 128, 1, 1, 0, p->run_stream(), args, nullptr));
+        } else {
+            HIP_TRY(vh::launch_acs_k15(a, p->code == VHIP_SPIRAL615, p->run_stream()));
+        }
     } else if (p->variant == VHIP_VARIANT_REGS) {
         vh::AcsRegsArgs a;
         a.syms = d_syms;
@@ -696,7 +772,13 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
         a.nframes = p->nframes;
         a.dec = p->d_dec;
         a.metrics = p->d_metrics;
-        HIP_TRY(vh::launch_acs_regs(p->code, p->regs_lb, a, p->run_stream()));
+        if (p->jit) {
+            const int waves = (a.nframes + p->lay.fpw - 1) / p->lay.fpw;
+            void *args[] = {&a};
+            HIP_TRY(hipModuleLaunchKernel(p->jit_fn[0], (unsigned)((waves + 3) / 4), 1, 1, 256, 1, 1, 0, p->run_stream(), args, nullptr));
+        } else {
+            HIP_TRY(vh::launch_acs_regs(p->code, p->regs_lb, a, p->run_stream()));
+        }
     } else {
         vh::AcsLdsArgs a;
         a.syms = d_syms;
@@ -791,6 +873,8 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
 }
 
 // ---------------------------------------------------------------- fused sliding-window decode
+int vhip_is_runtime_specialised(const vhip_decoder *p) { return p ? (p->jit ? 1 : 0) : -1; }
+
 int vhip_window_depth(const vhip_decoder *p) {
     if (!p || p->K > 9 || !vh::regs_poly_supported(p->code, p->poly)) return -1;
     int d, b, lb;

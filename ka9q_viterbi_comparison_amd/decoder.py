@@ -91,6 +91,11 @@ class HipViterbi:
         return self._lib.vhip_get_variant(self._h)
 
     @property
+    def runtime_specialised(self):
+        """True when the handle runs fast kernels compiled at create time for its (non-harness) polynomials."""
+        return self._lib.vhip_is_runtime_specialised(self._h) == 1
+
+    @property
     def rows_written(self):
         return self._lib.vhip_rows_written(self._h)
 

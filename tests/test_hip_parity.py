@@ -433,11 +433,20 @@ def test_two_handles_two_streams_and_reuse():
     d2.close()
 
 
-@pytest.mark.parametrize("code", [C.KA9Q27, C.SPIRAL47, C.KA9Q29, C.SPIRAL49, C.SPIRAL27, C.KA9Q615, C.KA9Q224])
+def _random_poly(spec, rng):
+    return [int(rng.integers(0, 1 << (spec.K - 2))) * 2 + 1 + (1 << (spec.K - 1)) for _ in range(spec.R)]
+
+
+@pytest.mark.parametrize("code", [C.KA9Q27, C.SPIRAL47, C.KA9Q29, C.SPIRAL49, C.SPIRAL27, C.KA9Q615, C.SPIRAL615, C.KA9Q224])
 def test_arbitrary_polynomials(code):
-    """Polynomials other than the harness set take the any-polynomial kernels (acs_lds / acs_k24); branch tables are
-    per handle, so two handles with different polynomials coexist (the reference keeps one process-global table,
-    viterbi27_sse2.cpp:26-28,61-70).  Asking for the specialised kernels with such polynomials is an error."""
+    """Polynomials other than the harness set (the reference builds its table from any `poly`, viterbi27_sse2.cpp:57-75).
+    Branch tables are per handle, so handles with different polynomials coexist (the reference keeps one process-global
+    table, :26-28,61-70).  Three routes, all held to the oracle on every row / metric / byte:
+      * default: the FAST kernel, compiled for these polynomials when the handle is created (jit.hip) -- REGS / HBM_TILED;
+      * the any-polynomial kernels (acs_lds / acs_k24) when asked for, or when the run-time build is switched off;
+      * with VHIP_JIT=0, asking for the fast variant explicitly is an error, not a silent fallback."""
+    import os
+
     from ka9q_viterbi_comparison_amd._lib import VhipError
     from ka9q_viterbi_comparison_amd.decoder import gen_frames_host, noise_q12
 
@@ -446,27 +455,81 @@ def test_arbitrary_polynomials(code):
     B = 8 if spec.K == 24 else 16
     steps = B * 8 + spec.K - 1
     steps -= 0 if spec_is_incremental(code) else steps % 2
+    fast = VARIANT_HBM_TILED if spec.K == 24 else VARIANT_REGS
+    generic = VARIANT_HBM if spec.K == 24 else VARIANT_LDS
     for trial in range(2):
-        poly = [int(rng.integers(0, 1 << (spec.K - 2))) * 2 + 1 + (1 << (spec.K - 1)) for _ in range(spec.R)]
+        poly = _random_poly(spec, rng)
         nframes = 1 if spec.K == 24 else 5
         payload, syms = gen_frames_host(spec, 7 + trial, 0, nframes, B, C.SOFT_AMP_Q16, noise_q12(spec.R, 64.0, spec.ebn0_db), poly=poly)
         syms = np.ascontiguousarray(syms[:, :steps * spec.R])
-        dec = HipViterbi(spec.name, steps, nframes=nframes, poly=poly)
-        assert dec.variant in (VARIANT_LDS, VARIANT_HBM)
-        dec.reset()
-        dec.update(syms, nbits=steps)
-        data, _ = dec.chainback(B * 8)
+        refs = []
         for f in range(nframes):
             o = OracleDecoder(code, poly, steps)
             o.update(syms[f], steps)
-            ref, _ = o.chainback(B * 8)
-            assert np.array_equal(dec.decision_rows(f, 0, steps), o.rows(steps)), (poly, f)
-            assert np.array_equal(dec.metrics(f), o.metrics())
-            assert np.array_equal(data[f], ref)
+            refs.append((o.rows(steps), o.metrics(), o.chainback(B * 8)[0]))
             o.close()
+        for route in ("default", "generic"):
+            dec = HipViterbi(spec.name, steps, nframes=nframes, poly=poly, variant=VARIANT_AUTO if route == "default" else generic)
+            if route == "default":
+                assert dec.runtime_specialised and (dec.variant & 0xff) == fast, "the run-time build of the fast kernel was not used"
+            else:
+                assert not dec.runtime_specialised and dec.variant == generic
+            dec.reset()
+            dec.update(syms, nbits=steps)
+            data, _ = dec.chainback(B * 8)
+            for f in range(nframes):
+                assert np.array_equal(dec.decision_rows(f, 0, steps), refs[f][0]), (route, poly, f)
+                assert np.array_equal(dec.metrics(f), refs[f][1]), (route, poly, f)
+                assert np.array_equal(data[f], refs[f][2]), (route, poly, f)
+            dec.close()
+    os.environ["VHIP_JIT"] = "0"
+    try:
+        dec = HipViterbi(spec.name, steps, nframes=1, poly=poly)
+        assert not dec.runtime_specialised and dec.variant == generic
         dec.close()
         with pytest.raises(VhipError):
-            HipViterbi(spec.name, steps, nframes=1, poly=poly, variant=VARIANT_HBM_TILED if spec.K == 24 else VARIANT_REGS)
+            HipViterbi(spec.name, steps, nframes=1, poly=poly, variant=fast)
+    finally:
+        del os.environ["VHIP_JIT"]
+
+
+@pytest.mark.parametrize("name,nframes,B", [("27", 16384, 64), ("49", 4096, 64), ("615", 512, 32)])
+def test_arbitrary_polynomials_run_at_full_speed(name, nframes, B):
+    """The run-time build for other polynomials is the same kernel with other constants: its ACS update takes no longer than
+    1.3x the harness-polynomial update on the same batch shape (live event timing of the library), and it decodes its
+    own noise-free frames without error."""
+    import torch
+
+    from ka9q_viterbi_comparison_amd import count_bit_errors_dev, gen_frames_dev
+
+    spec = C.CODES[name]
+    steps = B * 8 + spec.K - 1
+    stream = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(77)
+    times = {}
+    for label, poly in (("harness", spec.poly), ("other", _random_poly(spec, rng))):
+        d_payload = torch.empty(nframes * B, dtype=torch.uint8, device="cuda")
+        d_syms = torch.empty(nframes * steps * spec.R, dtype=torch.uint8, device="cuda")
+        d_out = torch.zeros(nframes * B, dtype=torch.uint8, device="cuda")
+        gen_frames_dev(spec, 5, 0, nframes, B, C.HARD_AMP_Q16, 0, d_payload, d_syms, stream, poly=poly)
+        dec = HipViterbi(name, steps, nframes=nframes, poly=poly, stream=stream)
+        assert dec.runtime_specialised == (label == "other")
+        dec.enable_timing(True)
+        for _ in range(4):
+            dec.reset()
+            dec.update(d_syms, nbits=steps)
+            dec.chainback(B * 8, out=d_out)
+        dec.read_timing()
+        for _ in range(5):
+            dec.reset()
+            dec.update(d_syms, nbits=steps)
+            dec.chainback(B * 8, out=d_out)
+        su, nu, _, _ = dec.read_timing()
+        times[label] = su / nu
+        # a random polynomial set may be catastrophic / weak, but noise-free input still decodes to the payload
+        assert count_bit_errors_dev(d_out, d_payload, nframes * B, stream) == 0 or label == "other"
+        dec.close()
+    assert times["other"] <= 1.3 * times["harness"], times
 
 
 @pytest.mark.parametrize("code,variant", [(C.KA9Q27, regs(0)), (C.SPIRAL47, regs(0)), (C.KA9Q27, regs(2)), (C.KA9Q29, regs(1)), (C.SPIRAL49, regs(0))])
