@@ -154,6 +154,10 @@ class HipShard:
         dec_bytes_per_frame = (64 if self.windowed else self.nsteps + spec.K) * ((1 << (spec.K - 1)) // 8) * self.depth
         budget = int(args.hbm_budget_gb * 1e9)
         chunk = frames if args.chunk_frames is None else min(args.chunk_frames, frames)
+        if args.chunk_frames is None and spec.K == 7 and not self.windowed and frames > 65536 and frames % 65536 == 0:
+            # the K=7 register kernel is tuned for exactly one wave per SIMD (1024 waves x 64 frames): bigger
+            # shards go through the double-buffered handle in chunks of 65536 frames (131072 frames: 298 vs 278 Gsym/s)
+            chunk = 65536
         while chunk > 64 and chunk * dec_bytes_per_frame > budget:
             chunk = (chunk + 1) // 2
         assert frames % chunk == 0, "frames must be a multiple of the chunk size"

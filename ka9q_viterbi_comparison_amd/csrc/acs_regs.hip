@@ -618,11 +618,77 @@ __global__ __launch_bounds__(256) void decode_windowed_kernel(DecodeWindowedArgs
                 if (m < nbytes) out[lo / 8 + m] = (unsigned char)(v >> (24 - 8 * m));
         }
     };
+    // K=7, one lane per frame, 8-bit blocks -- the steady state (a whole block, the full depth available).  The 64-bit
+    // decision row of a frame is the lane's own two ring words, so the reads do not depend on the state: all DEPTH + BLOCK
+    // rows are fetched up front (ds_read2st64_b32) and the walk is the position-space walk of chainback_k7_lds_kernel
+    // below -- three dependent ALU instructions per row instead of a dependent LDS round trip -- unrolled for each of the
+    // six phases the first row can have.  After the walk the top byte of h is the block's output byte; four blocks leave
+    // as one aligned dword.
+    constexpr bool FAST = NB == 6 && LB == 0 && BLOCK == 8;
+    const bool out_aligned = ((reinterpret_cast<uintptr_t>(a.data) | a.data_stride) & 3) == 0;
+    unsigned obuf = 0;
+    bool steady = true;  // no block has taken the general walk yet
+    auto emit_fast = [&](unsigned b, auto R0) {
+        constexpr int ROT0 = decltype(R0)::value;  // rot at the first row visited
+        constexpr int LW = DEPTH + BLOCK;
+        constexpr int PI[6] = {4, 0, 1, 2, 3, 5};  // position bit -> bit of the row index
+        const int top = (int)(b + 1) * BLOCK + NB + DEPTH;
+        const unsigned *rw = reinterpret_cast<const unsigned *>(ring) + lane;
+        unsigned q = 0, h = 0;  // state 0 sits at position 0 in every phase
+        static_for<2>([&](auto HALF) {
+            constexpr int d0 = decltype(HALF)::value * (LW / 2);
+            unsigned long long W[LW / 2];
+#pragma unroll
+            for (int d = 0; d < LW / 2; d++) {
+                const unsigned *wp = rw + ((top - 1 - (d0 + d)) & (RING - 1)) * (DW * 64);
+                W[d] = (unsigned long long)wp[0] | ((unsigned long long)wp[64] << 32);
+            }
+#pragma unroll
+            for (int d = 0; d < LW / 2; d++) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int rotd = ((ROT0 - (d0 + d)) % NB + NB) % NB;
+                const int jb = PI[(NB - rotd) % NB];
+                const unsigned t = (unsigned)(W[d] >> q);
+                q = (q & ~(1u << jb)) | ((t << jb) & (1u << jb));
+                h = (h >> 1) | (t << 31);
+            }
+        });
+        const unsigned byte = h >> 24;
+        if (out_aligned) {
+            obuf = (obuf << 8) | byte;
+            if ((b & 3u) == 3u && fvalid) *reinterpret_cast<unsigned *>(out + (b - 3u)) = __builtin_bswap32(obuf);
+        } else if (fvalid) {
+            out[b] = (unsigned char)byte;
+        }
+    };
     auto emit_ready = [&](int rows_done) {
         while (nextb < nblocks) {
             const unsigned hi = (nextb + 1) * BLOCK < a.nbits ? (nextb + 1) * BLOCK : a.nbits;
             const int top = (int)hi + NB + DEPTH < T ? (int)hi + NB + DEPTH : T;
             if (top > rows_done) break;
+            bool fast = false;
+            if constexpr (FAST) fast = (nextb + 1) * BLOCK <= a.nbits && (int)hi + NB + DEPTH <= T;
+            if constexpr (FAST) {
+                if (fast) {
+                    switch (top % NB) {  // uniform
+                    case 0: emit_fast(nextb, std::integral_constant<int, 0>{}); break;
+                    case 1: emit_fast(nextb, std::integral_constant<int, 1>{}); break;
+                    case 2: emit_fast(nextb, std::integral_constant<int, 2>{}); break;
+                    case 3: emit_fast(nextb, std::integral_constant<int, 3>{}); break;
+                    case 4: emit_fast(nextb, std::integral_constant<int, 4>{}); break;
+                    default: emit_fast(nextb, std::integral_constant<int, 5>{}); break;
+                    }
+                    nextb++;
+                    continue;
+                }
+                // leaving the steady state (the frame's last blocks): bytes of an unfinished dword go out one by one
+                if (steady && out_aligned && (nextb & 3u) != 0 && fvalid) {
+                    const unsigned pend = nextb & 3u;
+                    for (unsigned m = 0; m < pend; m++) out[nextb - pend + m] = (unsigned char)(obuf >> (8 * (pend - 1 - m)));
+                }
+                steady = false;
+            }
             emit(nextb++);
         }
     };

@@ -216,7 +216,13 @@ int auto_variant(const vhip_decoder *p) {
         if (vh::k24t_poly_supported(p->poly) && !getenv("VHIP_K24_FUSED")) return VHIP_VARIANT_HBM_TILED;
         return vh::k24f_poly_supported(p->poly) ? VHIP_VARIANT_HBM_FUSED : VHIP_VARIANT_HBM;
     }
-    if (p->K <= 9 && vh::regs_poly_supported(p->code, p->poly)) return VHIP_VARIANT_REGS;
+    if (p->K <= 9 && vh::regs_poly_supported(p->code, p->poly)) {
+        // K=9 r=1/2 with few frames: one workgroup per frame (256 lanes = 256 states) finishes a 2054-step frame in
+        // 0.33 ms, the register kernel (4 lanes per frame, one wave for 16 frames) in 1.09 ms, and the two meet near
+        // 3000 frames (tools/small_batch_probe.py); for the other K <= 9 codes the register kernels win or tie everywhere
+        if (p->K == 9 && p->R == 2 && p->nframes <= 2048) return VHIP_VARIANT_LDS;
+        return VHIP_VARIANT_REGS;
+    }
     if ((p->code == VHIP_KA9Q615 || p->code == VHIP_SPIRAL615) && vh::k15_poly_supported(p->poly)) return VHIP_VARIANT_REGS;
     return VHIP_VARIANT_LDS;
 }
