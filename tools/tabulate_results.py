@@ -28,21 +28,20 @@ def main():
     for title, num_key, den_key, unit in (("Symbol update", "total_output_symbols", "update_ns", "sym/s"),
                                           ("Chainback", "total_input_bytes", "chainback_ns", "bit/s")):
         print(f"### {title} ({unit})\n")
-        print("| K | R | frames | " + " | ".join(names) + " |")
-        print("|---|---|---|" + "---|" * len(names))
+        print("| K | R | " + " | ".join(f"{n} (frames per call)" for n in names) + " |")
+        print("|---|---|" + "---|" * len(names))
         for K, R in codes:
-            row, frames = [], ""
+            row = []
             for n in names:
                 m = [e for e in entries if e["name"] == n and (e["K"], e["R"]) == (K, R)]
                 if not m:
                     row.append("-")
                     continue
                 e = m[-1]
-                frames = str(e.get("frames", 1))
                 num = e[num_key] * (8 if den_key == "chainback_ns" else 1)
                 rate = num / (np.array(e[den_key], dtype=np.float64) * 1e-9)
-                row.append(f"{si(rate.mean())} ± {si(rate.std())}")
-            print(f"| {K} | {R} | {frames} | " + " | ".join(row) + " |")
+                row.append(f"{si(rate.mean())} ± {si(rate.std())} ({e.get('frames', 1)})")
+            print(f"| {K} | {R} | " + " | ".join(row) + " |")
         print()
 
 
