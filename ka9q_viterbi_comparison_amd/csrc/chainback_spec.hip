@@ -9,9 +9,14 @@
 // be in, and loads ITS decision bit from row i-d.  All 63 loads are in flight together; the true path is then
 // resolved with six v_readlane steps.  Six decoded bits per DRAM round trip instead of one, 63 four-byte loads
 // instead of six -- the history is far larger than the bytes touched either way.
+//
+// Two variants were built for K=24 in round 2 and dropped (bit-exact, slower than this kernel's 5.2 Mbit/s): rounds aligned with
+// the register groups of k24t_layout.h (inside a group the word offset of a row does not depend on the decisions, so one
+// 8-byte load per row covers the group and the group below can be speculated over <= 32 candidates: 8-10 decisions per round
+// trip, but the per-round index arithmetic and the serial resolve cost more than the round trips saved: 1.9 Mbit/s), and
+// touching the rows 96 steps ahead to warm their address translations (rows are 1 MiB apart: 4.8 Mbit/s, i.e. translation
+// misses are not what a round waits for).
 #include <hip/hip_runtime.h>
-
-#include <cstdlib>
 
 #include "k15_layout.h"
 #include "k24f_layout.h"
@@ -98,100 +103,6 @@ __global__ __launch_bounds__(64) void chainback_spec_kernel(ChainbackRowsArgs a)
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// K=24 over the two-pass layout (k24t_layout.h): rounds aligned with the kernels' register groups.
-//
-// Inside a register group (4-5 consecutive rows) the walk only replaces REGISTER bits of the position, so the two words a
-// thread wrote per row -- (tile, thread) of k24t_locate -- are the same for every row of the group whatever the decisions
-// are: one 8-byte load per row, all issued at once, covers the group.  The group below depends on this group's decisions
-// only through the (tile, thread) they select: at most 32 candidates, each again 8 bytes per row.  One round therefore
-// fetches group A (<= 5 loads) and every candidate of group B (<= 32 x 5 loads, three per lane) together and resolves 8-10
-// decisions per DRAM round trip instead of six, with a third of the load instructions of the binary tree above.
-// Same bytes out as chainback_viterbi224_sse2 (viterbi224_sse2.cpp:79-121).
-__global__ __launch_bounds__(64) void chainback_k24t_groups_kernel(ChainbackRowsArgs a) {
-    constexpr int NB = 23;
-    constexpr unsigned N = 1u << NB;
-    constexpr long ROWW = N / 32;  // words per row
-    const long f = blockIdx.x;
-    const unsigned lane = threadIdx.x;
-    const unsigned *rows = reinterpret_cast<const unsigned *>(a.dec + f * (long)a.cap_rows * (long)(N / 8));
-    unsigned char *out = a.data + f * (long)a.data_stride;
-    unsigned e = a.endstate & (N - 1u);
-    unsigned dbyte = 0;
-    long i = (long)a.nbits;  // rows i-1 ... 0 remain; row r <-> decoded bit r (no tail skip)
-
-    // the two words of the thread that holds position p at phase phi, as one 8-byte load (rows never written read as zero)
-    auto position = [&](long r, unsigned st) -> unsigned {  // where the decision of state st sits in row r
-        const int rot = (int)((r + 1) % NB);
-        return rot == 0 ? st : (((st >> rot) | (st << (NB - rot))) & (N - 1u));
-    };
-    // `p` = the position at the TOP row of r's register group: the lower rows of the group differ from it in register bits only
-    auto fetch = [&](long r, unsigned p) -> uint2 {
-        if (r < 0 || r >= a.rows_written) return make_uint2(0u, 0u);
-        unsigned w, b;
-        k24t_locate(p, (int)(r % NB), w, b);
-        return *reinterpret_cast<const uint2 *>(rows + r * ROWW + (w & ~1u));
-    };
-    auto bit_of = [&](long r, unsigned st, uint2 v) -> unsigned {
-        const int rot = (int)((r + 1) % NB), phi = (int)(r % NB);
-        const unsigned p = rot == 0 ? st : (((st >> rot) | (st << (NB - rot))) & (N - 1u));
-        unsigned w, b;
-        k24t_locate(p, phi, w, b);
-        return (((w & 1u) ? v.y : v.x) >> b) & 1u;
-    };
-    auto step_out = [&](unsigned k) {  // viterbi224_sse2.cpp:96-103 for row i-1
-        --i;
-        dbyte = ((e & 1u) << 7) | (dbyte >> 1);
-        if ((i & 7) == 0 && lane == 0) out[i >> 3] = (unsigned char)dbyte;
-        e = (k << (NB - 1)) | (e >> 1);
-    };
-
-    while (i > 0) {
-        // group A: rows i-1 ... down to the first row of its register group (na rows); group B: the whole group below (nb rows)
-        const long ra = i - 1;
-        const int ga = k24t_group_of_phase((int)(ra % NB));
-        const int na = (int)(ra % NB) - k24t_first_phase(ga) + 1 < (int)i ? (int)(ra % NB) - k24t_first_phase(ga) + 1 : (int)i;
-        const long rb = ra - na;  // top row of group B (may be < 0)
-        int nb = 0;
-        if (rb >= 0) {
-            const int gb = k24t_group_of_phase((int)(rb % NB));
-            nb = k24t_nphases(gb);  // rb is the LAST phase of its group: the group below A starts where A ended
-            if (nb > rb + 1) nb = (int)(rb + 1);
-        }
-        const unsigned ncand = 1u << na;
-        // loads: lane l < na takes row ra - l of group A; candidate c, row j of group B is item c * nb + j
-        uint2 va = make_uint2(0u, 0u);
-        if ((int)lane < na) va = fetch(ra - lane, position(ra, e));  // (tile, thread) of the top row hold for every row of the group
-        uint2 vb[3] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
-        const unsigned items = nb > 0 ? ncand * (unsigned)nb : 0u;
-#pragma unroll
-        for (int s3 = 0; s3 < 3; s3++) {
-            const unsigned it = lane + 64u * s3;
-            if (it < items) {
-                const unsigned c = it / (unsigned)nb, j = it % (unsigned)nb;
-                const unsigned ec = (e >> na) | (c << (NB - na));  // state after na steps with decisions c (first decision = bit 0)
-                vb[s3] = fetch(rb - (long)j, position(rb, ec));
-            }
-        }
-        // resolve group A
-        unsigned c = 0;
-        for (int s = 0; s < na; s++) {
-            const uint2 v = make_uint2((unsigned)__builtin_amdgcn_readlane((int)va.x, s), (unsigned)__builtin_amdgcn_readlane((int)va.y, s));
-            // the words were fetched with the top state's (tile, thread); the bit inside them follows the current state
-            const unsigned k = bit_of(ra - s, e, v);
-            c |= k << s;
-            step_out(k);
-        }
-        // resolve group B out of candidate c
-        for (int j = 0; j < nb; j++) {
-            const unsigned it = c * (unsigned)nb + (unsigned)j, src = it & 63u, s3 = it >> 6;
-            const unsigned x = s3 == 0 ? vb[0].x : s3 == 1 ? vb[1].x : vb[2].x, y = s3 == 0 ? vb[0].y : s3 == 1 ? vb[1].y : vb[2].y;
-            const uint2 v = make_uint2((unsigned)__builtin_amdgcn_readlane((int)x, (int)src), (unsigned)__builtin_amdgcn_readlane((int)y, (int)src));
-            step_out(bit_of(rb - j, e, v));
-        }
-    }
-}
-
 hipError_t launch_chainback_spec(int layout, const ChainbackRowsArgs &a, hipStream_t stream) {
     const dim3 grid(a.nframes), block(64);
     if (a.K == 15 && layout == LAY_NATURAL) hipLaunchKernelGGL((chainback_spec_kernel<LAY_NATURAL, 15, false>), grid, block, 0, stream, a);
@@ -199,8 +110,7 @@ hipError_t launch_chainback_spec(int layout, const ChainbackRowsArgs &a, hipStre
     else if (a.K == 15 && layout == LAY_K15_SIGN_BYTES) hipLaunchKernelGGL((chainback_spec_kernel<LAY_K15_SIGN_BYTES, 15, false>), grid, block, 0, stream, a);
     else if (a.K == 24 && layout == LAY_NATURAL) hipLaunchKernelGGL((chainback_spec_kernel<LAY_NATURAL, 24, true>), grid, block, 0, stream, a);
     else if (a.K == 24 && layout == LAY_K24F) hipLaunchKernelGGL((chainback_spec_kernel<LAY_K24F, 24, true>), grid, block, 0, stream, a);
-    else if (a.K == 24 && layout == LAY_K24T && getenv("VHIP_CHAINBACK_TREE")) hipLaunchKernelGGL((chainback_spec_kernel<LAY_K24T, 24, true>), grid, block, 0, stream, a);
-    else if (a.K == 24 && layout == LAY_K24T) hipLaunchKernelGGL(chainback_k24t_groups_kernel, grid, block, 0, stream, a);
+    else if (a.K == 24 && layout == LAY_K24T) hipLaunchKernelGGL((chainback_spec_kernel<LAY_K24T, 24, true>), grid, block, 0, stream, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
