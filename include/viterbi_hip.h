@@ -64,8 +64,8 @@ int vhip_chainback(vhip_decoder *p, unsigned char *data, unsigned int nbits, uns
 /* device-pointer, asynchronous on the handle's stream (inputs already resident in HBM).
  * Exception -- VHIP_KA9Q224: vhip_update_dev BLOCKS the calling thread until the update has been enqueued to its end.  The
  * K=24 renormalisation (viterbi224_sse2.cpp:226-246) is run speculatively, several multi-step passes ahead of the device,
- * and the host has to follow the passes' progress word to commit or replay them; with nframes > 1 the frames are spread
- * over three internal streams driven by three host threads for the duration of the call.  vhip_init and
+ * and the host has to follow the passes' progress word to commit or replay them; with nframes > 1 three frames at a time
+ * are in flight on internal streams, all driven by the calling thread (no helper threads).  vhip_init and
  * vhip_chainback_dev stay asynchronous. */
 int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits);
 int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbits, unsigned int endstate);

@@ -307,20 +307,48 @@ bool k24_multistep(int variant) { return variant == VHIP_VARIANT_HBM_FUSED || va
 // K=24 multi-step passes: rows are grouped by phase = row mod 23 into passes of 4,4,4,4,7 steps (acs_k24f.hip) or of
 // 9,14 steps (acs_k24t.hip).
 //
-// Speculative renormalisation (DESIGN.md §4.6): passes are enqueued ahead of the device, DEPTH at a time, and every pass
+// Speculative renormalisation (DESIGN.md §4.7): passes are enqueued ahead of the device, DEPTH at a time, and every pass
 // stores (its sequence number, the sticky flag word) into one pinned host word when its flag-owning thread is done.  The
 // host follows the stream by polling that word -- no event, no stream wait, so nothing but kernels enters the stream -- and
 // commits each pass whose rows lie before the raised row.  When a pass raised the flag, every later pass has returned at
 // once (it sees a flag of an earlier row); the stream is drained, the raising pass is replayed up to the flagged row, the
 // metrics are renormalised and the pipeline restarts behind that row.
-int k24f_update_frame(vhip_decoder *p, int f, const unsigned char *d_syms, int steps, int row0, hipStream_t stream, int *flags) {
-    const bool tiled = p->variant == VHIP_VARIANT_HBM_TILED;
-    const size_t NN = p->N;
-    int16_t *buf[2] = {p->d_metrics + (size_t)f * 2 * NN, p->d_metrics + (size_t)f * 2 * NN + NN};
-    unsigned char *rows = p->d_dec + (size_t)f * p->cap_rows * p->row_bytes;
-    int cur = p->k24_cur[f];
+//
+// One K24Run is the update of one frame on one stream as a resumable state machine: pump() enqueues what fits, looks at
+// the progress word and returns, so ONE host thread keeps several frames in flight on several streams (vhip_update_dev
+// with nframes > 1) -- no helper threads.
+struct K24Run {
     struct Pass { int g, s_lo, s_hi, rel, in; unsigned seq; };  // rel = index in this call of the row of stage s_lo
-    auto group_of = [tiled](int phi, int &first, int &np) {
+    vhip_decoder *p = nullptr;
+    int f = -1, steps = 0, row0 = 0, slot = 0;
+    const unsigned char *d_syms = nullptr;
+    hipStream_t stream = nullptr;
+    int *flags = nullptr;
+    bool tiled = false;
+    int16_t *buf[2] = {nullptr, nullptr};
+    unsigned char *rows = nullptr;
+    int cur = 0, t = 0, tt = 0, c = 0;  // committed buffer / rows committed / next row to enqueue / its input buffer
+    size_t depth = 6;
+    std::deque<Pass> inflight;
+    unsigned spins = 0;
+
+    void start(vhip_decoder *h, int frame, const unsigned char *syms, int nsteps, int first_row, hipStream_t st, int *fl) {
+        p = h; f = frame; d_syms = syms; steps = nsteps; row0 = first_row; stream = st; flags = fl;
+        tiled = h->variant == VHIP_VARIANT_HBM_TILED;
+        const size_t NN = h->N;
+        buf[0] = h->d_metrics + (size_t)frame * 2 * NN;
+        buf[1] = buf[0] + NN;
+        rows = h->d_dec + (size_t)frame * h->cap_rows * h->row_bytes;
+        cur = c = h->k24_cur[frame];
+        t = tt = 0;
+        slot = (int)((fl - h->d_flags) / 4);  // 0: handle stream, 1..: the internal streams
+        // passes kept enqueued: enough work (>= ~100 us) for the host to see a report and enqueue the next pass, no more --
+        // every pass behind a raised flag is cancelled work (it still streams part of its tile in)
+        depth = tiled ? 6 : 12;
+        inflight.clear();
+        spins = 0;
+    }
+    int group_of(int phi, int &first, int &np) const {
         if (tiled) {
             const int pass = vh::k24t_pass_of_phase(phi);
             first = vh::k24t_pass_first(pass);
@@ -329,13 +357,10 @@ int k24f_update_frame(vhip_decoder *p, int f, const unsigned char *d_syms, int s
         }
         if (phi < 16) { first = (phi / 4) * 4; np = 4; return phi / 4; }
         first = 16; np = 7; return 4;
-    };
-    const int slot = (int)((flags - p->d_flags) / 4);  // 0: handle stream, 1..: the worker streams
-    volatile unsigned long long *h_word = p->h_report + slot;
-    unsigned long long *d_word = p->h_report_dev + slot;
-    auto launch = [&](const Pass &q, bool report) -> int {
+    }
+    int launch(const Pass &q, bool report) {
         const long row_g0 = (long)row0 + q.rel - q.s_lo;  // absolute row of the group's phase 0 (may precede row0)
-        const vh::K24Report rep{report ? d_word : nullptr, q.seq};
+        const vh::K24Report rep{report ? p->h_report_dev + slot : nullptr, q.seq};
         if (tiled && p->jit) {
             // the run-time build of acs_k24t.hip for this handle's polynomials: same arguments, same grids as launch_k24t_pass
             const int16_t *oldm = buf[q.in];
@@ -348,69 +373,113 @@ int k24f_update_frame(vhip_decoder *p, int f, const unsigned char *d_syms, int s
             void *args[] = {&oldm, &newm, &rw, &sy, &rel0, &s_lo, &s_hi, &fl, &rp};
             const bool full = s_lo == 0 && s_hi == vh::k24t_pass_nphases(q.g);
             HIP_TRY(hipModuleLaunchKernel(p->jit_fn[q.g * 2 + (full ? 0 : 1)], q.g == 0 ? 256 : 512, 1, 1, q.g == 0 ? 512 : 256, 1, 1, 0, stream, args, nullptr));
-        } else if (tiled)
+        } else if (tiled) {
             HIP_TRY(vh::launch_k24t_pass(q.g, buf[q.in], buf[q.in ^ 1], rows + row_g0 * (long)p->row_bytes,
                                          d_syms + ((long)q.rel - q.s_lo) * 2, q.rel - q.s_lo, q.s_lo, q.s_hi, flags, rep, stream));
-        else
+        } else {
             HIP_TRY(vh::launch_k24f_pass(q.g, buf[q.in], buf[q.in ^ 1], rows + row_g0 * (long)p->row_bytes,
                                          d_syms + ((long)q.rel - q.s_lo) * 2, q.rel - q.s_lo, q.s_lo, q.s_hi, flags, rep, stream));
+        }
         return 0;
-    };
-    // passes kept enqueued: enough work (>= ~100 us) for the host to see a report and enqueue the next pass, no more --
-    // every pass behind a raised flag is cancelled work (it still streams part of its tile in)
-    const size_t DEPTH = tiled ? 6 : 12;
-    std::deque<Pass> inflight;
-    int t = 0;        // rows of this call committed so far
-    int tt = 0, c = cur;  // next row / buffer to enqueue
-    unsigned &seq = p->k24_seq[slot];
-    while (t < steps) {
-        while (inflight.size() < DEPTH && tt < steps) {
-            const int phi = (row0 + tt) % 23;
-            int first, np;
-            const int g = group_of(phi, first, np);
-            Pass ps{g, phi - first, std::min(np, phi - first + (steps - tt)), tt, c, ++seq};
-            if (launch(ps, true) != 0) return -1;
-            inflight.push_back(ps);
-            tt += ps.s_hi - ps.s_lo;
-            c ^= 1;
-        }
-        // wait for the oldest pass in flight to report
-        const Pass &front = inflight.front();
-        unsigned long long w;
-        unsigned spins = 0;
-        while ((int)((unsigned)((w = *h_word) >> 32) - front.seq) < 0) {
-            if ((++spins & 0xfffu) == 0) {
-                // a device fault would leave the word unchanged for ever: ask the runtime now and then
-                const hipError_t qe = hipStreamQuery(stream);
-                if (qe != hipSuccess && qe != hipErrorNotReady) return fail("K=24: stream failed while waiting for a pass", qe);
-                if (qe == hipSuccess && (int)((unsigned)(*h_word >> 32) - front.seq) < 0) return fail("K=24: pass finished without reporting");
-            }
-            std::this_thread::yield();
-        }
-        const int pending = (int)(unsigned)(w & 0xffffffffull);
-        const int adv = front.s_hi - front.s_lo;
-        if (pending == 0 || pending - 1 >= front.rel + adv) {  // no flag, or raised by a later row: this pass stands
-            t = front.rel + adv;
-            cur = front.in ^ 1;
-            inflight.pop_front();
-            continue;
-        }
-        const int rr = pending - 1;  // renormalise after this row of the call
-        if (rr < front.rel) return fail("K=24: renormalisation flag out of range");
-        HIP_TRY(hipStreamSynchronize(stream));  // the younger passes have returned at once
-        HIP_TRY(vh::launch_k24_flags_reset(flags, stream));
-        Pass redo = front;
-        redo.s_hi = redo.s_lo + (rr - redo.rel) + 1;  // replay the raising pass up to and including row rr
-        redo.seq = ++seq;
-        if (launch(redo, false) != 0) return -1;
-        cur = redo.in ^ 1;
-        HIP_TRY(vh::launch_k24_renorm(buf[cur], flags, stream));  // min-reduce, wrapping subtract, clear flags
-        t = rr + 1;
-        tt = t;
-        c = cur;
-        inflight.clear();  // restart the pipeline behind the renormalised row
     }
-    p->k24_cur[f] = cur;
+    // 1: the frame is complete (everything it needs is enqueued and committed); 0: waiting for the device; -1: error
+    int pump() {
+        volatile unsigned long long *h_word = p->h_report + slot;
+        unsigned &seq = p->k24_seq[slot];
+        for (;;) {
+            if (t >= steps) {
+                p->k24_cur[f] = cur;
+                return 1;
+            }
+            while (inflight.size() < depth && tt < steps) {
+                const int phi = (row0 + tt) % 23;
+                int first, np;
+                const int g = group_of(phi, first, np);
+                Pass ps{g, phi - first, std::min(np, phi - first + (steps - tt)), tt, c, ++seq};
+                if (launch(ps, true) != 0) return -1;
+                inflight.push_back(ps);
+                tt += ps.s_hi - ps.s_lo;
+                c ^= 1;
+            }
+            const Pass front = inflight.front();
+            const unsigned long long w = *h_word;
+            if ((int)((unsigned)(w >> 32) - front.seq) < 0) {  // the oldest pass in flight has not reported yet
+                if ((++spins & 0x3fffu) == 0) {
+                    // a device fault would leave the word unchanged for ever: ask the runtime now and then
+                    const hipError_t qe = hipStreamQuery(stream);
+                    if (qe != hipSuccess && qe != hipErrorNotReady) return fail("K=24: stream failed while waiting for a pass", qe);
+                    if (qe == hipSuccess && (int)((unsigned)(*h_word >> 32) - front.seq) < 0) return fail("K=24: pass finished without reporting");
+                }
+                return 0;
+            }
+            spins = 0;
+            const int pending = (int)(unsigned)(w & 0xffffffffull);
+            const int adv = front.s_hi - front.s_lo;
+            if (pending == 0 || pending - 1 >= front.rel + adv) {  // no flag, or raised by a later row: this pass stands
+                t = front.rel + adv;
+                cur = front.in ^ 1;
+                inflight.pop_front();
+                continue;
+            }
+            const int rr = pending - 1;  // renormalise after this row of the call
+            if (rr < front.rel) return fail("K=24: renormalisation flag out of range");
+            HIP_TRY(hipStreamSynchronize(stream));  // the younger passes have returned at once
+            HIP_TRY(vh::launch_k24_flags_reset(flags, stream));
+            Pass redo = front;
+            redo.s_hi = redo.s_lo + (rr - redo.rel) + 1;  // replay the raising pass up to and including row rr
+            redo.seq = ++seq;
+            if (launch(redo, false) != 0) return -1;
+            cur = redo.in ^ 1;
+            HIP_TRY(vh::launch_k24_renorm(buf[cur], flags, stream));  // min-reduce, wrapping subtract, clear flags
+            t = rr + 1;
+            tt = t;
+            c = cur;
+            inflight.clear();  // restart the pipeline behind the renormalised row
+        }
+    }
+};
+
+int k24f_update_frame(vhip_decoder *p, int f, const unsigned char *d_syms, int steps, int row0, hipStream_t stream, int *flags) {
+    K24Run run;
+    run.start(p, f, d_syms, steps, row0, stream, flags);
+    int rc;
+    while ((rc = run.pump()) == 0) std::this_thread::yield();
+    return rc < 0 ? -1 : 0;
+}
+
+// several frames: up to K24_WORKERS of them in flight, one internal stream each, all pumped by the calling thread
+int k24f_update_frames(vhip_decoder *p, const unsigned char *d_syms, size_t sym_stride, int steps, int row0) {
+    constexpr int W = vhip_decoder::K24_WORKERS;
+    K24Run runs[W];
+    bool active[W] = {};
+    int next = 0, live = 0;
+    for (int w = 0; w < W; w++) HIP_TRY(vh::launch_k24_flags_reset(p->d_flags + 4 * (w + 1), p->aux_stream[w]));
+    while (next < p->nframes || live > 0) {
+        bool progressed = false;
+        for (int w = 0; w < W; w++) {
+            if (!active[w]) {
+                if (next >= p->nframes) continue;
+                runs[w].start(p, next, d_syms + (size_t)next * sym_stride, steps, row0, p->aux_stream[w], p->d_flags + 4 * (w + 1));
+                next++;
+                active[w] = true;
+                live++;
+            }
+            const int rc = runs[w].pump();
+            if (rc < 0) {
+                for (int v = 0; v < W; v++) (void)hipStreamSynchronize(p->aux_stream[v]);
+                return -1;
+            }
+            if (rc == 1) {
+                active[w] = false;
+                live--;
+                progressed = true;
+            }
+        }
+        if (!progressed) std::this_thread::yield();
+    }
+    // a pass reports when its flag-owning thread is done, not when its last workgroup is: drain the internal streams so that
+    // whatever the caller enqueues next on the handle's stream (the chainback) finds every decision row in place
+    for (int w = 0; w < W; w++) HIP_TRY(hipStreamSynchronize(p->aux_stream[w]));
     return 0;
 }
 
@@ -724,26 +793,10 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
     } time_scope{timing_begin(p, p->t_upd, p->run_stream()), p->run_stream()};
     if (p->code == VHIP_KA9Q224) {
         if (k24_multistep(p->variant) && p->nframes > 1) {
-            // A single K=24 decode leaves the chip under-occupied between its load/compute/store phases (two concurrent
-            // decodes run 1.47x faster than two serial ones), so K24_WORKERS frames are decoded at a time: one host thread
-            // each, with its own stream and flag words, frames interleaved between them.
+            // A single K=24 decode leaves the chip under-occupied between its load / compute / store phases (three decodes
+            // in flight run 2x faster per frame than one), so K24_WORKERS frames are decoded at a time on internal streams.
             HIP_TRY(hipStreamSynchronize(p->stream));  // the caller's symbols are ready
-            constexpr int W = vhip_decoder::K24_WORKERS;
-            int rcs[W] = {};
-            std::string errs[W];
-            std::thread th[W];
-            for (int w = 0; w < W; w++)
-                th[w] = std::thread([&, w]() {
-                    if (hipSetDevice(p->device) != hipSuccess) { rcs[w] = -1; return; }
-                    int *flags = p->d_flags + 4 * (w + 1);
-                    if (vh::launch_k24_flags_reset(flags, p->aux_stream[w]) != hipSuccess) { rcs[w] = -1; return; }
-                    for (int f = w; f < p->nframes && rcs[w] == 0; f += W)
-                        rcs[w] = k24f_update_frame(p, f, d_syms + (size_t)f * sym_stride, steps, row0, p->aux_stream[w], flags);
-                    if (rcs[w] != 0) errs[w] = vhip_last_error();
-                });
-            for (int w = 0; w < W; w++) th[w].join();
-            for (int w = 0; w < W; w++)
-                if (rcs[w] != 0) return fail(errs[w].empty() ? "K=24 worker failed" : errs[w].c_str());
+            if (k24f_update_frames(p, d_syms, sym_stride, steps, row0) != 0) return -1;
         } else {
             for (int f = 0; f < p->nframes; f++) {
                 const int rc = k24_multistep(p->variant)
