@@ -51,3 +51,28 @@ def test_reference_style_bindings_decode():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all bindings ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_harness_reference_methodology_mode(tmp_path):
+    """--host-api: the reference's own loop (src/main.cpp:257-280) -- one frame per handle, host buffers, the blocking
+    reference-shaped calls -- at the reference's frame sizes; same JSON schema, noise-free input decodes without error."""
+    out = tmp_path / "host.json"
+    r = subprocess.run([BIN, "-t", "0.05", "-n", "2", "-o", str(out), "--host-api", "--hard", "--codes", "27,49,615,224"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    entries = json.load(open(out))
+    assert [(e["K"], e["R"]) for e in entries] == [(7, 2), (9, 4), (15, 6), (24, 2)]
+    for e in entries:
+        for k in REF_KEYS:
+            assert k in e, k
+        assert e["name"] == "hip_host_1frame" and e["frames"] == 1
+        assert e["total_input_bytes"] == {7: 1024, 9: 512, 15: 256, 24: 8}[e["K"]]  # src/main.cpp:366,395,404,414
+        assert e["total_samples"] == len(e["update_ns"]) >= 3 and e["total_bit_errors"] == 0
+
+
+def test_harness_rejects_zero_time_and_zero_samples():
+    """src/main.cpp:344-351: sampling time must be positive, minimum samples non-zero (checked before any device use)."""
+    for flags in (["-t", "0"], ["-t", "-1"], ["-n", "0"]):
+        r = subprocess.run([BIN] + flags, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 1, (flags, r.returncode, r.stderr)
