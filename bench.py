@@ -333,7 +333,10 @@ def main():
             rate = vv["valu_wave_instr_per_launch"] / (upd_ms * 1e-3) / 1e9
             valu = {"wave_instr_per_launch": vv["valu_wave_instr_per_launch"], "achieved_ginstr_per_s": round(rate, 2),
                     "issue_ceiling_ginstr_per_s": round(vv["issue_ceiling_ginstr_per_s"], 2),
-                    "frac": round(rate / vv["issue_ceiling_ginstr_per_s"], 4), "source": vsrc}
+                    "frac": round(rate / vv["issue_ceiling_ginstr_per_s"], 4),
+                    # the same kernel with nothing else on the device (roofline.alone)
+                    "frac_alone": round(vv["valu_wave_instr_per_launch"] / (st["update_ms_alone"] * 1e-3) / 1e9 / vv["issue_ceiling_ginstr_per_s"], 4),
+                    "source": vsrc}
         out = {
             "metric": f"Msymbols/s decoded, K={spec.K} r=1/{spec.R} " + ("(fused sliding-window decode: NOT the reference chainback semantics)" if shard.windowed else "(init + ACS update + chainback)"),
             "value": round(core["value"] / 1e6, 6),
