@@ -95,10 +95,11 @@ int vhip_enable_timing(vhip_decoder *p, int on);
 int vhip_read_timing(vhip_decoder *p, double *update_ms_sum, int *n_update, double *chainback_ms_sum, int *n_chainback);
 
 /* Fused sliding-window decode (additive): init + ACS update + traceback in ONE kernel for the K <= 9
- * codes with the harness polynomials.  The decisions of the last 64 trellis steps live in an LDS ring; as soon as the row
- * vhip_window_depth() steps beyond a block of vhip_window_block() payload bits exists, the block is traced back out of the
- * ring (start state 0) and its bytes are stored -- no decision history and no path metrics ever reach HBM, so the handle's
- * history buffer is not used and the batch size is not bounded by it.  d_syms: nframes frames of (nbits + K - 1) * R
+ * and K = 15 codes with the harness polynomials.  The decisions of the last trellis steps live in a ring -- 64 rows in LDS
+ * for K <= 9, 160 rows of a cache-resident global buffer per resident workgroup for K = 15 (320 MiB at most, whatever the
+ * batch) --; as soon as the row vhip_window_depth() steps beyond a block of vhip_window_block() payload bits exists, the
+ * block is traced back out of the ring (start state 0) and its bytes are stored -- no decision history and no path metrics
+ * ever reach HBM, so the handle's history buffer is not used and the batch size is not bounded by it.  d_syms: nframes frames of (nbits + K - 1) * R
  * symbols from a freshly initialised decoder (start state 0); d_data: ceil(nbits/8) bytes per frame, MSB-first.
  * Results are those of a sliding-window Viterbi decoder -- NOT bit-identical to init/update/chainback unless the depth
  * covers the frame (the error rate converges on the exact path's as the depth grows: tests/test_windowed.py).  There is no

@@ -260,23 +260,103 @@ struct Smem {
     int red[4];       // per-wave minima (double-buffered by row parity in the spiral flavour)
 };
 
-template <bool SP>
-__device__ __forceinline__ void acs_k15_body(const AcsK15Args &a) {
+// Fused sliding-window decode (the K=15 half): the WIN instantiation of the body below runs the same
+// trellis steps from freshly initialised metrics, but its decision rows go to a workgroup-private RING of the last WIN_RING
+// rows in global memory -- 320 KiB per resident workgroup, at most 1024 of them: the ring lives in the L2 / Infinity Cache,
+// and the 4.2 MB-per-frame history of the exact path is never written -- and whenever the row WIN_DEPTH steps beyond a block
+// of WIN_BLOCK payload bits exists, wave 0 walks that block out of the ring with the speculative tree of chainback_spec.hip
+// (start state 0; six decisions per cache round trip) and stores its four bytes.  Semantics:
+// oracle/viterbi_oracle.c vo_chainback_windowed (depth 96, blocks of 32 bits).
+constexpr int WIN_DEPTH = 96, WIN_BLOCK = 32, WIN_RING = 160;  // 160 rows x 2 KiB = 320 KiB per resident workgroup
+static_assert(WIN_DEPTH + WIN_BLOCK + 2 * NB <= WIN_RING, "ring too small");
+struct DecodeWindowedK15Args {
+    const unsigned char *syms;
+    size_t sym_stride;
+    int nsteps, nframes;
+    unsigned char *data;
+    size_t data_stride;
+    unsigned nbits;
+    unsigned *ring;  // [gridDim.x][WIN_RING][512] words
+};
+
+// one block of the windowed traceback, by ONE wave: payload bits [lo, hi) walked from row top-1 (state 0) down to row lo+NB
+template <bool SIGN_BYTES>
+__device__ __forceinline__ unsigned walk_block_k15(const unsigned *ring, int top, unsigned lo, unsigned hi, unsigned lane) {
+    constexpr int DEPTH = 6;
+    const unsigned node = lane + 1;
+    const int d = 31 - __clz(node);
+    const unsigned path = node - (1u << d);
+    const bool live = lane < 63;
+    unsigned st0 = 0, v = 0;
+    int i = top - NB;  // payload-bit index + 1 of the first row visited (row = bit + NB)
+    while (i > (int)lo) {
+        unsigned st = st0;
+        for (int s = 0; s < DEPTH - 1; s++)
+            if (s < d) st = (st >> 1) | (((path >> (d - 1 - s)) & 1u) << (NB - 1));
+        const int bi = i - 1 - d;
+        unsigned k = 0;
+        if (live && bi >= (int)lo) {
+            const int r = bi + NB;
+            const int rot = (r + 1) % NB;
+            const unsigned p = rot == 0 ? st : (((st >> rot) | (st << (NB - rot))) & (N - 1u));
+            const int phi = rot == 0 ? NB - 1 : rot - 1;
+            const unsigned t = phi < 7 ? (p & 127u) : (p >> 7), q = phi < 7 ? (p >> 7) : (p & 127u);
+            const unsigned rho = q >> 1, h = q & 1u;
+            // written by this workgroup a moment ago: read past the (not yet refreshed) vector L1
+            const unsigned w = __builtin_nontemporal_load(ring + (long)(r % WIN_RING) * 512 + (rho >> 4) * 128 + t);
+            k = (w >> k15_decision_bit(SIGN_BYTES, rho, h)) & 1u;
+        }
+        unsigned cur = 1;
+        const int left = i - (int)lo, nres = left < DEPTH ? left : DEPTH;
+        for (int s = 0; s < nres; s++) {
+            const unsigned kb = (unsigned)__builtin_amdgcn_readlane((int)k, (int)(cur - 1)) & 1u;
+            --i;
+            st0 = (st0 >> 1) | (kb << (NB - 1));
+            if (i < (int)hi) v |= kb << (31 - (i - (int)lo));  // MSB-first inside the block
+            cur = 2 * cur + kb;
+        }
+    }
+    return v;
+}
+
+// WIN = false: the exact path (AcsK15Args).  WIN = true: the fused windowed decode (DecodeWindowedK15Args), persistent
+// over frames blockIdx.x, blockIdx.x + gridDim.x, ...
+template <bool SP, bool WIN, class Args>
+__device__ __forceinline__ void acs_k15_body(const Args &a) {
     __shared__ Smem sm;
     const SignMasks sgm;
     const unsigned tid = threadIdx.x;
-    const long f = blockIdx.x;
-    const int row0 = a.row0, row_end = a.row0 + a.nsteps;
-    const int phi0 = row0 % NB;
-    int16_t *gm = a.metrics + f * (long)N;
-    for (unsigned p = tid; p < (unsigned)N; p += THREADS) {
-        const unsigned st = phi0 == 0 ? p : (((p << phi0) | (p >> (NB - phi0))) & (N - 1u));
-        sm.img[p] = SP ? (int16_t)(((unsigned)gm[st] << 8) | 0xffu) : gm[st];  // spiral: (m<<8)|0xff fields
+  for (long f = blockIdx.x; f < (WIN ? (long)a.nframes : (long)blockIdx.x + 1); f += gridDim.x) {
+    int row0, row_end, phi0;
+    int16_t *gm = nullptr;
+    unsigned *drow = nullptr;
+    unsigned *ring = nullptr;
+    if constexpr (WIN) {
+        row0 = 0;
+        row_end = a.nsteps;
+        phi0 = 0;
+        ring = a.ring + (long)blockIdx.x * WIN_RING * 512;
+        // init_viterbi615_sse2 (viterbi615_sse2.cpp:33-39): every state init_all, state 0 init_start; spiral: (m<<8)|0xff fields
+        using CT = std::conditional_t<SP, Spiral615, Code615>;
+        const int ia = SP ? (int)(((unsigned)CT::init_all << 8) | 0xffu) : CT::init_all;
+        const int is = SP ? (int)(((unsigned)CT::init_start << 8) | 0xffu) : CT::init_start;
+        __syncthreads();  // the previous frame's last reads of the image are done
+        for (unsigned p = tid; p < (unsigned)N; p += THREADS) sm.img[p] = (int16_t)(p == 0 ? is : ia);
+    } else {
+        row0 = a.row0;
+        row_end = a.row0 + a.nsteps;
+        phi0 = row0 % NB;
+        gm = a.metrics + f * (long)N;
+        for (unsigned p = tid; p < (unsigned)N; p += THREADS) {
+            const unsigned st = phi0 == 0 ? p : (((p << phi0) | (p >> (NB - phi0))) & (N - 1u));
+            sm.img[p] = SP ? (int16_t)(((unsigned)gm[st] << 8) | 0xffu) : gm[st];  // spiral: (m<<8)|0xff fields
+        }
+        drow = reinterpret_cast<unsigned *>(a.dec) + (f * a.cap_rows + row0) * 512L + tid;
     }
     const unsigned char *sp = a.syms + f * (long)a.sym_stride;
     const long lim = (long)a.nsteps * R;
     const bool aligned = ((reinterpret_cast<uintptr_t>(a.syms) | a.sym_stride) & 3) == 0 && ((phi0 * R) & 3) == 0;
-    unsigned *drow = reinterpret_cast<unsigned *>(a.dec) + (f * a.cap_rows + row0) * 512L + tid;
+    unsigned nextb = 0;  // WIN: next block to emit
     __syncthreads();
 
     i16x2 M[NR];
@@ -334,9 +414,15 @@ __device__ __forceinline__ void acs_k15_body(const AcsK15Args &a) {
                     }
                     unsigned words[4];
                     stage<SP, PHI>(M, sraw, tid, words, sgm);
+                    if constexpr (WIN) {
+                        unsigned *rr = ring + (long)(r % WIN_RING) * 512 + tid;
 #pragma unroll
-                    for (int w = 0; w < 4; w++) __builtin_nontemporal_store(words[w], drow + w * 128);  // written once, read much later
-                    drow += 512;
+                        for (int w = 0; w < 4; w++) rr[w * 128] = words[w];
+                    } else {
+#pragma unroll
+                        for (int w = 0; w < 4; w++) __builtin_nontemporal_store(words[w], drow + w * 128);  // written once, read much later
+                        drow += 512;
+                    }
                     if constexpr (SP) {
                         // spiral615.cpp:31-40,269: if new[0] > 74 subtract the minimum -- it fires on nearly every step,
                         // so the workgroup minimum is formed unconditionally behind the one barrier of the step
@@ -394,18 +480,45 @@ __device__ __forceinline__ void acs_k15_body(const AcsK15Args &a) {
         };
         run_group(std::integral_constant<int, 0>{});
         run_group(std::integral_constant<int, 1>{});
+        if constexpr (WIN) {
+            // every block whose top row now exists; the last barrier of run_group has drained this period's ring stores
+            const int rows_done = rbase + NB < row_end ? rbase + NB : row_end;
+            const unsigned nblocks = (a.nbits + WIN_BLOCK - 1) / WIN_BLOCK;
+            while (nextb < nblocks) {
+                const unsigned lo = nextb * WIN_BLOCK, hi = lo + WIN_BLOCK < a.nbits ? lo + WIN_BLOCK : a.nbits;
+                const int top = (int)hi + NB + WIN_DEPTH < row_end ? (int)hi + NB + WIN_DEPTH : row_end;
+                if (top > rows_done) break;
+                if (tid < 64) {  // wave 0 walks; wave 1 waits at the next period's first barrier
+                    const unsigned v = walk_block_k15<!SP>(ring, top, lo, hi, tid);
+                    if (tid == 0) {
+                        unsigned char *out = a.data + f * (long)a.data_stride + lo / 8;
+                        const unsigned nbytes = (hi - lo + 7) / 8;
+                        for (unsigned m = 0; m < nbytes; m++) out[m] = (unsigned char)(v >> (24 - 8 * m));
+                    }
+                }
+                nextb++;
+            }
+        }
     }
 
-    const int phie = row_end % NB;
-    for (unsigned p = tid; p < (unsigned)N; p += THREADS) {
-        const unsigned st = phie == 0 ? p : (((p << phie) | (p >> (NB - phie))) & (N - 1u));
-        gm[st] = SP ? (int16_t)(((unsigned)(unsigned short)sm.img[p]) >> 8) : sm.img[p];
+    if constexpr (!WIN) {
+        const int phie = row_end % NB;
+        for (unsigned p = tid; p < (unsigned)N; p += THREADS) {
+            const unsigned st = phie == 0 ? p : (((p << phie) | (p >> (NB - phie))) & (N - 1u));
+            gm[st] = SP ? (int16_t)(((unsigned)(unsigned short)sm.img[p]) >> 8) : sm.img[p];
+        }
     }
+  }
 }
 
 template <bool SP>
 __global__ __launch_bounds__(THREADS, 2) void acs_k15_kernel(AcsK15Args a) {
-    acs_k15_body<SP>(a);
+    acs_k15_body<SP, false>(a);
+}
+
+template <bool SP>
+__global__ __launch_bounds__(THREADS, 2) void decode_windowed_k15_kernel(DecodeWindowedK15Args a) {
+    acs_k15_body<SP, true>(a);
 }
 
 #ifndef VH_JIT_KERNEL
@@ -453,6 +566,21 @@ hipError_t launch_acs_k15(const AcsK15Args &a, bool spiral, hipStream_t stream) 
     return hipGetLastError();
 }
 
+// fused windowed decode: a persistent grid of at most 1024 workgroups (four per CU), each with its own decision ring
+size_t windowed_k15_ring_bytes(int nframes) { return (size_t)(nframes < 1024 ? nframes : 1024) * k15::WIN_RING * 2048; }
+void windowed_k15_params(int *depth, int *block) {
+    *depth = k15::WIN_DEPTH;
+    *block = k15::WIN_BLOCK;
+}
+hipError_t launch_decode_windowed_k15(bool spiral, const unsigned char *syms, size_t sym_stride, int nsteps, int nframes, unsigned char *data,
+                                      size_t data_stride, unsigned nbits, unsigned *ring, hipStream_t stream) {
+    const k15::DecodeWindowedK15Args a{syms, sym_stride, nsteps, nframes, data, data_stride, nbits, ring};
+    const int grid = nframes < 1024 ? nframes : 1024;
+    if (spiral) hipLaunchKernelGGL(k15::decode_windowed_k15_kernel<true>, dim3(grid), dim3(k15::THREADS), 0, stream, a);
+    else hipLaunchKernelGGL(k15::decode_windowed_k15_kernel<false>, dim3(grid), dim3(k15::THREADS), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_chainback_k15(const ChainbackRowsArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL(k15::chainback_k15_kernel, dim3((a.nframes + 63) / 64), dim3(64), 0, stream, a);
     return hipGetLastError();
@@ -463,5 +591,5 @@ hipError_t launch_chainback_k15(const ChainbackRowsArgs &a, hipStream_t stream) 
 }  // namespace vh
 
 #ifdef VH_JIT_KERNEL
-extern "C" __global__ __launch_bounds__(128, 2) void vh_jit_acs_k15(vh::AcsK15Args a) { vh::k15::acs_k15_body<VH_JIT_SPIRAL>(a); }
+extern "C" __global__ __launch_bounds__(128, 2) void vh_jit_acs_k15(vh::AcsK15Args a) { vh::k15::acs_k15_body<VH_JIT_SPIRAL, false>(a); }
 #endif

@@ -93,6 +93,11 @@ struct AcsK15Args {
 };
 struct ChainbackRowsArgs;
 bool k15_poly_supported(const int *poly);
+// fused sliding-window decode for K=15 (harness polynomials): decision ring of the resident workgroups in global memory
+size_t windowed_k15_ring_bytes(int nframes);
+void windowed_k15_params(int *depth, int *block);
+hipError_t launch_decode_windowed_k15(bool spiral, const unsigned char *syms, size_t sym_stride, int nsteps, int nframes, unsigned char *data,
+                                      size_t data_stride, unsigned nbits, unsigned *ring, hipStream_t stream);
 hipError_t launch_acs_k15(const AcsK15Args &a, bool spiral, hipStream_t stream);  // spiral: the spiral615 arithmetic
 hipError_t launch_chainback_k15(const ChainbackRowsArgs &a, hipStream_t stream);
 

@@ -72,6 +72,8 @@ struct vhip_decoder {
     size_t syms_stage_bytes = 0;
     unsigned char *d_data_stage = nullptr;
     size_t data_stage_bytes = 0;
+    unsigned char *d_ring = nullptr;  // K=15 fused windowed decode: decision rings of the resident workgroups
+    size_t ring_bytes = 0;
     int pos = 0;
     std::vector<int> k24_cur;  // per frame: which half of the ping-pong holds the current metrics
     int regs_lb = 0;           // REGS variant: log2(lanes per frame)
@@ -609,6 +611,7 @@ void vhip_delete(vhip_decoder *p) {
     if (p->h_report) (void)hipHostFree(p->h_report);
     if (p->d_syms_stage) (void)hipFree(p->d_syms_stage);
     if (p->d_data_stage) (void)hipFree(p->d_data_stage);
+    if (p->d_ring) (void)hipFree(p->d_ring);
     delete p;
 }
 
@@ -934,24 +937,33 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
 // ---------------------------------------------------------------- fused sliding-window decode
 int vhip_is_runtime_specialised(const vhip_decoder *p) { return p ? (p->jit ? 1 : 0) : -1; }
 
+namespace {
+bool window_params(const vhip_decoder *p, int *depth, int *block) {
+    if (!p) return false;
+    if (p->K == 15 && vh::k15_poly_supported(p->poly)) {
+        vh::windowed_k15_params(depth, block);
+        return true;
+    }
+    if (p->K > 9 || !vh::regs_poly_supported(p->code, p->poly)) return false;
+    int lb;
+    vh::windowed_params(p->code, depth, block, &lb);
+    return true;
+}
+}  // namespace
 int vhip_window_depth(const vhip_decoder *p) {
-    if (!p || p->K > 9 || !vh::regs_poly_supported(p->code, p->poly)) return -1;
-    int d, b, lb;
-    vh::windowed_params(p->code, &d, &b, &lb);
-    return d;
+    int d, b;
+    return window_params(p, &d, &b) ? d : -1;
 }
 int vhip_window_block(const vhip_decoder *p) {
-    if (!p || p->K > 9 || !vh::regs_poly_supported(p->code, p->poly)) return -1;
-    int d, b, lb;
-    vh::windowed_params(p->code, &d, &b, &lb);
-    return b;
+    int d, b;
+    return window_params(p, &d, &b) ? b : -1;
 }
 
 int vhip_decode_windowed_dev(vhip_decoder *p, const unsigned char *d_syms, unsigned int nbits, unsigned char *d_data) {
     StatusScope status_scope(p);
     if (!p) return fail("decode_windowed: NULL handle");
     if (use_device(p) != 0) return -1;
-    if (vhip_window_depth(p) < 0) return fail("decode_windowed: built for K <= 9 with the harness polynomials");
+    if (vhip_window_depth(p) < 0) return fail("decode_windowed: built for K <= 9 and K = 15 with the harness polynomials");
     if (nbits == 0) return 0;
     const int steps = (int)nbits + p->K - 1;
     if (steps > p->cap_rows) return fail("decode_windowed: more trellis steps than the handle was created for");
@@ -962,6 +974,14 @@ int vhip_decode_windowed_dev(vhip_decoder *p, const unsigned char *d_syms, unsig
         ~TimeScope() { timing_end(e1, st); }
     } time_scope{timing_begin(p, p->t_upd, p->run_stream()), p->run_stream()};
     const int steps_run = p->incremental ? steps : (steps / 2) * 2;  // update_spiral47 drops an odd last step (spiral47.cpp:536-538)
+    if (p->K == 15) {
+        // the decision ring of the resident workgroups (320 KiB each, at most 1024): allocated on first use, kept with the handle
+        const size_t need = vh::windowed_k15_ring_bytes(p->nframes);
+        if (ensure_stage(&p->d_ring, &p->ring_bytes, need, &p->total_bytes) != 0) return -1;
+        HIP_TRY(vh::launch_decode_windowed_k15(p->code == VHIP_SPIRAL615, d_syms, (size_t)steps * p->R, steps_run, p->nframes, d_data, (nbits + 7) / 8,
+                                               nbits, reinterpret_cast<unsigned *>(p->d_ring), p->run_stream()));
+        return 0;
+    }
     HIP_TRY(vh::launch_decode_windowed(p->code, d_syms, (size_t)steps * p->R, steps_run, p->nframes, d_data, (nbits + 7) / 8, nbits, p->run_stream()));
     return 0;
 }

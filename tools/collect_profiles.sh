@@ -56,6 +56,8 @@ python3 bench.py --code 224 --frames 12 --payload-bits 64 --steps 2 --warmup 1 -
 echo "shard-size lines done"
 : > $P/${TAG}_windowed_decode.jsonl
 for c in 27 47 29 49; do python3 bench.py --code $c --windowed --steps 20 --warmup 3 --no-cpu-baseline 2>> $O/shard.err | tail -n 1 >> $P/${TAG}_windowed_decode.jsonl; done
+for c in 615 spiral615; do python3 bench.py --code $c --windowed --steps 5 --warmup 1 --no-cpu-baseline 2>> $O/shard.err | tail -n 1 >> $P/${TAG}_windowed_decode.jsonl; done
+python3 bench.py --code 615 --windowed --frames 131072 --steps 1 --warmup 1 --no-cpu-baseline 2>> $O/shard.err | tail -n 1 >> $P/${TAG}_windowed_decode.jsonl
 python3 bench.py --code 27 --windowed --frames 1048576 --steps 3 --warmup 1 --no-cpu-baseline 2>> $O/shard.err | tail -n 1 >> $P/${TAG}_windowed_decode.jsonl
 echo "windowed lines done"
 ./harness/viterbi_bench -t 1.0 -n 8 -o $P/${TAG}_harness_default.json > $O/harness.log 2>&1
