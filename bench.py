@@ -162,7 +162,7 @@ class HipShard:
             chunk = (chunk + 1) // 2
         assert frames % chunk == 0, "frames must be a multiple of the chunk size"
         self.chunk, self.nchunks = chunk, frames // chunk
-        # the fused decode keeps its decisions in LDS: the handle then only needs a token history buffer
+        # the fused decode keeps its decisions in an on-chip / cache-resident ring: such a handle never allocates a history
         self.dec = HipViterbi(args.code, self.nsteps, nframes=chunk, variant=args.variant, stream=self.stream.cuda_stream,
                               pipeline_depth=self.depth)
         self.dec.enable_timing(True)

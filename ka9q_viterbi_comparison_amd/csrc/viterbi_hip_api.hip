@@ -193,6 +193,22 @@ void timing_end(hipEvent_t e1, hipStream_t st) {
     if (e1) (void)hipEventRecord(e1, st);
 }
 
+// decision history of the current buffer set: allocated and zeroed on first use (rows never written read as zero)
+int ensure_history(vhip_decoder *p) {
+    if (p->d_dec) return 0;
+    const size_t dec_bytes = (size_t)p->frames_padded * (size_t)p->cap_rows * p->row_bytes;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&p->d_dec), dec_bytes ? dec_bytes : 16);
+    if (e != hipSuccess) {
+        p->d_dec = nullptr;
+        return fail("decision history allocation (frames x steps x 2^(K-1)/8 bytes; the fused windowed decode needs none)", e);
+    }
+    e = hipMemsetAsync(p->d_dec, 0, dec_bytes ? dec_bytes : 16, p->run_stream());
+    if (e != hipSuccess) return fail("decision history memset", e);
+    p->total_bytes += dec_bytes;
+    if (p->depth > 1) p->slots[p->cur_slot].d_dec = p->d_dec;
+    return 0;
+}
+
 int sync_all(vhip_decoder *p) {
     for (int i = 0; i < p->depth && p->depth > 1; i++) HIP_TRY(hipStreamSynchronize(p->slots[i].stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -550,10 +566,10 @@ vhip_decoder *vhip_create(int code, const int *poly, int len, int nframes) {
     }
     const size_t dec_bytes = (size_t)p->frames_padded * (size_t)p->cap_rows * p->row_bytes;
     const size_t met_bytes = (size_t)nframes * p->N * sizeof(int16_t) * (code == VHIP_KA9Q224 ? 2 : 1);
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&p->d_dec), dec_bytes ? dec_bytes : 16);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_metrics), met_bytes);
+    // The decision history is allocated by the first call that needs it (ensure_history): a handle that is only ever used
+    // for the fused windowed decode never holds one, so its batch is not bounded by N/8 bytes per frame-step.
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&p->d_metrics), met_bytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_flags), sizeof(int) * 32);
-    if (e == hipSuccess) e = hipMemset(p->d_dec, 0, dec_bytes ? dec_bytes : 16);
     if (e == hipSuccess) e = hipMemset(p->d_flags, 0, sizeof(int) * 32);
     if (e != hipSuccess) {
         fail("create: device allocation", e);
@@ -572,7 +588,8 @@ vhip_decoder *vhip_create(int code, const int *poly, int len, int nframes) {
         vhip_delete(p);
         return nullptr;
     }
-    p->total_bytes = dec_bytes + met_bytes + 64;
+    p->total_bytes = met_bytes + 64;
+    (void)dec_bytes;
     p->k24_cur.assign(nframes, 0);
     if (vhip_init(p, 0) != 0) {
         vhip_delete(p);
@@ -670,6 +687,7 @@ int vhip_set_pipeline_depth(vhip_decoder *p, int depth) {
     if (p->depth != 1 || p->pos != 0) return fail("set_pipeline_depth: only once, on a fresh handle");
     if (depth == 1) return 0;
     if (p->code == VHIP_KA9Q224) return fail("set_pipeline_depth: K=24 handles keep several frames in flight by themselves");
+    if (ensure_history(p) != 0) return -1;
     HIP_TRY(hipStreamSynchronize(p->stream));
     const size_t dec_bytes = (size_t)p->frames_padded * (size_t)p->cap_rows * p->row_bytes;
     const size_t met_bytes = (size_t)p->nframes * p->N * sizeof(int16_t);
@@ -789,6 +807,7 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
     if (row0 + steps > p->cap_rows) return fail("update: more trellis steps than the handle was created for");
     const size_t sym_stride = (size_t)nbits * p->R;
     if (order_behind_caller(p) != 0) return -1;
+    if (ensure_history(p) != 0) return -1;
     struct TimeScope {  // the closing event is recorded on every path out of the launches below
         hipEvent_t e1;
         hipStream_t st;
@@ -864,6 +883,7 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
     if (use_device(p) != 0) return -1;
     if (nbits == 0) return 0;
     if (order_behind_caller(p) != 0) return -1;
+    if (ensure_history(p) != 0) return -1;
     struct TimeScope {
         hipEvent_t e1;
         hipStream_t st;
@@ -1028,6 +1048,7 @@ int vhip_read_decision_rows(vhip_decoder *p, int frame, int row0, int nrows, uns
     if (use_device(p) != 0) return -1;
     if (frame < 0 || frame >= p->nframes || row0 < 0 || nrows < 0 || row0 + nrows > p->cap_rows)
         return fail("read_decision_rows: out of range");
+    if (ensure_history(p) != 0) return -1;
     if (sync_all(p) != 0) return -1;
     if (k24_multistep(p->variant)) {
         // position bitmap of acs_k24f.hip / acs_k24t.hip -> natural bitmap

@@ -123,3 +123,28 @@ def test_fused_decode_full_batch_error_rate_and_no_history(name, frames_):
     limit = 4.0 if spec.K == 9 else 1.15
     assert e_exact * 0.8 <= e_win <= e_exact * limit + 50, (e_win, e_exact)
     dec.close()
+
+
+@pytest.mark.gpu
+def test_fused_decode_handle_holds_no_history():
+    """A handle that is only used for the fused decode never allocates the N/8-bytes-per-frame-step decision history (it is
+    allocated by the first update / chainback that needs it): 65536 K=15 frames would need 278 GB of it; the fused decode
+    of a (short) batch that size runs in a few hundred MiB."""
+    import torch
+
+    from ka9q_viterbi_comparison_amd import HipViterbi, count_bit_errors_dev, gen_frames_dev
+
+    spec = C.CODES["615"]
+    frames_, bits = 65536, 64
+    B, steps = bits // 8, bits + spec.K - 1
+    stream = torch.cuda.current_stream().cuda_stream
+    dec = HipViterbi("615", 2062, nframes=frames_, stream=stream)  # created for full-length frames: history would be 278 GB
+    assert dec.device_bytes < 4 << 30
+    d_payload = torch.empty(frames_ * B, dtype=torch.uint8, device="cuda")
+    d_syms = torch.empty(frames_ * steps * spec.R, dtype=torch.uint8, device="cuda")
+    d_out = torch.zeros(frames_ * B, dtype=torch.uint8, device="cuda")
+    gen_frames_dev(spec, 9, 0, frames_, B, C.HARD_AMP_Q16, 0, d_payload, d_syms, stream)
+    dec.decode_windowed(d_syms, bits, d_out)
+    assert count_bit_errors_dev(d_out, d_payload, frames_ * B, stream) == 0
+    assert dec.device_bytes < 4 << 30
+    dec.close()
