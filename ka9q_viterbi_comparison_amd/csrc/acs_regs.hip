@@ -696,13 +696,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     };
 
     int rbase = 0;
-    while (rbase < T) {
-        const bool full = rbase + NB <= T;
+    const int nfull = T / NB;
+    if (aligned && nfull > 0) {
+        // whole periods: the next period's symbols are fetched while this one computes (as acs_regs_body; without the
+        // prefetch every period waits out a memory round trip: 1.13 instead of 0.93 ms for the trellis part of config 2)
+        const long last_off = (long)(nfull - 1) * NB * R;
+        long off = 0;
+        unsigned cur[SW], nxt[SW];
+        load_period_fast<SW>(sp, 0, cur);
+#pragma unroll
+        for (int w = 0; w < SW; w++) asm volatile("" : "+v"(cur[w]));
+        for (int i = 0; i < nfull; i++) {
+            const long noff = off + NB * R < last_off ? off + NB * R : last_off;  // clamped: no branch around the load
+            load_period_fast<SW>(sp, noff, nxt);
+            run_period<C, P, LB, false>(M, cur, rbase, 0, T, lam, sink);
+#pragma unroll
+            for (int w = 0; w < SW; w++) cur[w] = nxt[w];
+            off += NB * R;
+            rbase += NB;
+            emit_ready(rbase);
+        }
+    }
+    while (rbase < T) {  // the last partial period, or symbols that are not dword aligned
         unsigned cur[SW];
-        if (aligned && full) load_period_fast<SW>(sp, (long)rbase * R, cur);
-        else load_period_guarded<SW>(sp, (long)rbase * R, lim, cur);
-        if (full) run_period<C, P, LB, false>(M, cur, rbase, 0, T, lam, sink);
-        else run_period<C, P, LB, true>(M, cur, rbase, 0, T, lam, sink);
+        load_period_guarded<SW>(sp, (long)rbase * R, lim, cur);
+        run_period<C, P, LB, true>(M, cur, rbase, 0, T, lam, sink);
         rbase += NB;
         emit_ready(rbase < T ? rbase : T);
     }
