@@ -63,6 +63,7 @@ echo "windowed lines done"
 ./harness/viterbi_bench -t 1.0 -n 8 -o $P/${TAG}_harness_default.json > $O/harness.log 2>&1
 ./harness/viterbi_bench -t 1.0 -n 8 --host-api --hard -o $P/${TAG}_harness_host_1frame.json >> $O/harness.log 2>&1
 python3 tools/tabulate_results.py $P/${TAG}_harness_default.json $P/${TAG}_harness_host_1frame.json > $P/${TAG}_harness_tables.md 2>> $O/harness.log
+make -C tools > /dev/null 2>&1
 ./tools/valu_rate > $P/${TAG}_valu_rate.txt 2>&1
 ./tools/sstore_rate > $P/${TAG}_sstore_rate.txt 2>&1
 ./tools/icache_probe > $P/${TAG}_icache_probe.txt 2>&1
