@@ -88,6 +88,17 @@ int vhip_set_pipeline_depth(vhip_decoder *p, int depth);
 int vhip_get_pipeline_depth(const vhip_decoder *p);
 int vhip_join(vhip_decoder *p);
 
+/* Chainback of the K >= 15 codes with at most 64 frames per handle: one frame's traceback is a chain of dependent DRAM round
+ * trips, so it is cut into segments of `seg_bits` decoded bits (a multiple of 8) that separate waves walk at the same time,
+ * each from a guessed state `warmup_rows` rows above its segment; the guesses are then verified against the exact walk from
+ * the caller's end state downwards and every segment whose guess had not merged is walked again, so the bytes are always
+ * those of chainback_viterbi615_sse2 / chainback_viterbi224_sse2 (viterbi615_sse2.cpp:65-91, viterbi224_sse2.cpp:79-121).
+ * seg_bits = 0: one walk per frame; negative values: the defaults (64 / 160).
+ * vhip_chainback_rewalked: segments the last chainback had to walk twice (summed over frames; blocks until it is done);
+ * *nseg = segments per frame of that chainback, 0 if it ran as one walk. */
+int vhip_set_chainback_segments(vhip_decoder *p, int seg_bits, int warmup_rows);
+int vhip_chainback_rewalked(vhip_decoder *p, int *nseg);
+
 /* Live kernel timing.  When enabled, every vhip_update_dev / vhip_chainback_dev is bracketed by HIP events on the stream
  * its kernels run on (the handle's stream, or the internal stream of the current pipeline slot).  vhip_read_timing waits
  * for the handle to go idle and returns the summed durations (ms) and launch counts since the previous read. */

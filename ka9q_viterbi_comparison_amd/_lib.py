@@ -60,6 +60,8 @@ SYMBOLS = [
     ("vhip_set_pipeline_depth", C.c_int, [C.c_void_p, C.c_int]),
     ("vhip_get_pipeline_depth", C.c_int, [C.c_void_p]),
     ("vhip_join", C.c_int, [C.c_void_p]),
+    ("vhip_set_chainback_segments", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    ("vhip_chainback_rewalked", C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     ("vhip_set_variant", C.c_int, [C.c_void_p, C.c_int]),
     ("vhip_get_variant", C.c_int, [C.c_void_p]),
     ("vhip_is_runtime_specialised", C.c_int, [C.c_void_p]),

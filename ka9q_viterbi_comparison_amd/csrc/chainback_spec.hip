@@ -53,15 +53,15 @@ __device__ __forceinline__ unsigned fetch_bit(const unsigned char *rows, long r,
     }
 }
 
-template <int LAY, int K, bool K224>
-__global__ __launch_bounds__(64) void chainback_spec_kernel(ChainbackRowsArgs a) {
+// One wave walks decoded-bit indices i = i_from, i_from-1, ..., i_to+1 (the register `e` is the reference's own: the state,
+// shifted for K < 9) and returns the register it ends with.  OUT: bytes are stored as the reference stores them (every
+// time i reaches a multiple of 8); a walk without OUT only carries the register forward.
+template <int LAY, int K, bool K224, bool OUT>
+__device__ __forceinline__ unsigned spec_walk(const ChainbackRowsArgs &a, const unsigned char *rows, unsigned char *out, unsigned e,
+                                              long i_from, long i_to) {
     constexpr int NB = K - 1, DEPTH = 6;
-    constexpr unsigned N = 1u << NB;
     constexpr int add = (NB < 8) ? 8 - NB : 0, sub = (NB > 8) ? NB - 8 : 0;
-    const long f = blockIdx.x;
     const unsigned lane = threadIdx.x;
-    const unsigned char *rows = a.dec + f * (long)a.cap_rows * (long)(N / 8);
-    unsigned char *out = a.data + f * (long)a.data_stride;
     const long tail = K224 ? 0 : NB;  // chainback_viterbi224_sse2 does not skip the tail rows
 
     // tree node of this lane: depth d, assumed bits b_1..b_d = bits d-1..0 of `path` (first assumed bit = MSB)
@@ -70,10 +70,9 @@ __global__ __launch_bounds__(64) void chainback_spec_kernel(ChainbackRowsArgs a)
     const unsigned path = node - (1u << d);
     const bool live = lane < 63;
 
-    unsigned e = K224 ? (a.endstate & (N - 1u)) : ((a.endstate % N) << add);  // the reference's own register
     unsigned dbyte = 0;
-    long i = (long)a.nbits;  // bits i-1 ... 0 remain
-    while (i > 0) {
+    long i = i_from;  // bits i-1 ... i_to remain
+    while (i > i_to) {
         const unsigned st0 = K224 ? e : (e >> add);
         // state this lane would be in after its d assumed decisions
         unsigned st = st0;
@@ -81,36 +80,119 @@ __global__ __launch_bounds__(64) void chainback_spec_kernel(ChainbackRowsArgs a)
             if (s < d) st = (st >> 1) | (((path >> (d - 1 - s)) & 1u) << (NB - 1));
         const long bi = i - 1 - d;  // decoded-bit index this lane serves
         unsigned k = 0;
-        if (live && bi >= 0 && bi + tail < a.rows_written) k = fetch_bit<LAY, K>(rows, bi + tail, st);
+        if (live && bi >= i_to && bi + tail < a.rows_written) k = fetch_bit<LAY, K>(rows, bi + tail, st);
         // resolve the true path: node 1 -> 2*node + k
         unsigned cur = 1;
-        const int nres = i < DEPTH ? (int)i : DEPTH;
+        const int nres = i - i_to < DEPTH ? (int)(i - i_to) : DEPTH;
         for (int s = 0; s < nres; s++) {
             const unsigned kb = (unsigned)__builtin_amdgcn_readlane((int)k, (int)(cur - 1)) & 1u;
             --i;
             if (K224) {
                 // viterbi224_sse2.cpp:96-103
                 dbyte = ((e & 1u) << 7) | (dbyte >> 1);
-                if ((i & 7) == 0 && lane == 0) out[i >> 3] = (unsigned char)dbyte;
+                if (OUT && (i & 7) == 0 && lane == 0) out[i >> 3] = (unsigned char)dbyte;
                 e = (kb << (K - 2)) | (e >> 1);
             } else {
                 // viterbi615_sse2.cpp:86-88 / spiral47.cpp:116-118
                 e = (e >> 1) | (kb << (K - 2 + add));
-                if ((i & 7) == 0 && lane == 0) out[i >> 3] = (unsigned char)(e >> sub);
+                if (OUT && (i & 7) == 0 && lane == 0) out[i >> 3] = (unsigned char)(e >> sub);
             }
             cur = 2 * cur + kb;
         }
     }
+    return e;
+}
+
+template <int K, bool K224>
+__device__ __forceinline__ unsigned spec_first_register(unsigned endstate) {
+    constexpr int NB = K - 1;
+    constexpr unsigned N = 1u << NB;
+    constexpr int add = (NB < 8) ? 8 - NB : 0;
+    return K224 ? (endstate & (N - 1u)) : ((endstate % N) << add);  // the reference's own register
+}
+
+template <int LAY, int K, bool K224>
+__global__ __launch_bounds__(64) void chainback_spec_kernel(ChainbackRowsArgs a) {
+    constexpr unsigned N = 1u << (K - 1);
+    const long f = blockIdx.x;
+    const unsigned char *rows = a.dec + f * (long)a.cap_rows * (long)(N / 8);
+    unsigned char *out = a.data + f * (long)a.data_stride;
+    (void)spec_walk<LAY, K, K224, true>(a, rows, out, spec_first_register<K, K224>(a.endstate), (long)a.nbits, 0);
+}
+
+// Segment-parallel form for FEW frames (K=24: one frame; the reference-style one-frame handles of K=15), where the walk above is a
+// single chain of DRAM round trips.  The frame's nbits are cut into segments of seg_bits; segment j is walked by its own wave
+// from i = hi_j + seg_ovl with a GUESSED register (0): tracebacks from any state merge with the survivor path, so after the
+// seg_ovl warm-up rows the register is, almost always, the one the full walk has at i = hi_j.  "Almost always" is not
+// bit-exact, so it is never trusted: every wave records the register it had at hi_j and the one it ended with at lo_j, and the
+// last wave of the frame to finish (an atomic ticket; nobody waits for anybody) checks the chain from the top segment -- which
+// starts from the caller's end state and is exact -- downwards: where the register a segment assumed at hi_j differs from the
+// one the segment above really ended with, that segment is walked again from the true register, overwriting its bytes.  The walk
+// is a deterministic function of (i, register), so equal registers at hi_j prove the segment's bytes.
+template <int LAY, int K, bool K224>
+__global__ __launch_bounds__(64) void chainback_spec_seg_kernel(ChainbackRowsArgs a) {
+    constexpr unsigned N = 1u << (K - 1);
+    const int nseg = a.nseg;
+    const long f = blockIdx.x / nseg;
+    const int j = nseg - 1 - (int)(blockIdx.x % nseg);  // top segment first
+    const unsigned char *rows = a.dec + f * (long)a.cap_rows * (long)(N / 8);
+    unsigned char *out = a.data + f * (long)a.data_stride;
+    // scratch: [frame][ticket, re-walked segments] at a place that does not depend on the geometry (the ticket must read 0 when a
+    // launch begins, whatever the previous launch's nseg was), then [frame][assumed[nseg], ended[nseg]]
+    unsigned *tk = a.seg_scratch + f * 2;
+    unsigned *sc = a.seg_scratch + 2 * (long)a.nframes + f * (long)(2 * nseg);
+    const long lo = (long)j * a.seg_bits;
+    const long hi = lo + a.seg_bits < (long)a.nbits ? lo + a.seg_bits : (long)a.nbits;
+
+    unsigned e;
+    if (hi + a.seg_ovl >= (long)a.nbits) e = spec_walk<LAY, K, K224, false>(a, rows, out, spec_first_register<K, K224>(a.endstate), (long)a.nbits, hi);
+    else e = spec_walk<LAY, K, K224, false>(a, rows, out, 0u, hi + a.seg_ovl, hi);
+    const unsigned assumed = e;
+    e = spec_walk<LAY, K, K224, true>(a, rows, out, e, hi, lo);
+
+    unsigned ticket = 0;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(sc + j, assumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sc + nseg + j, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);  // releases the bytes and the two words
+    }
+    ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+    if (ticket != (unsigned)(nseg - 1)) return;
+
+    // last wave of this frame: every other segment's words and bytes are visible
+    unsigned truth = __hip_atomic_load(sc + nseg + (nseg - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned rewalked = 0;
+    for (int s = nseg - 2; s >= 0; s--) {
+        const unsigned as = __hip_atomic_load(sc + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (as == truth) {
+            truth = __hip_atomic_load(sc + nseg + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const long slo = (long)s * a.seg_bits;
+            truth = spec_walk<LAY, K, K224, true>(a, rows, out, truth, slo + a.seg_bits, slo);
+            rewalked++;
+        }
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(tk + 1, rewalked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ticket counter ready for the next launch
+    }
+}
+
+template <int LAY, int K, bool K224>
+static void launch_spec(const ChainbackRowsArgs &a, hipStream_t stream) {
+    if (a.seg_scratch && a.nseg > 1)
+        hipLaunchKernelGGL((chainback_spec_seg_kernel<LAY, K, K224>), dim3((unsigned)a.nframes * (unsigned)a.nseg), dim3(64), 0, stream, a);
+    else
+        hipLaunchKernelGGL((chainback_spec_kernel<LAY, K, K224>), dim3(a.nframes), dim3(64), 0, stream, a);
 }
 
 hipError_t launch_chainback_spec(int layout, const ChainbackRowsArgs &a, hipStream_t stream) {
-    const dim3 grid(a.nframes), block(64);
-    if (a.K == 15 && layout == LAY_NATURAL) hipLaunchKernelGGL((chainback_spec_kernel<LAY_NATURAL, 15, false>), grid, block, 0, stream, a);
-    else if (a.K == 15 && layout == LAY_K15) hipLaunchKernelGGL((chainback_spec_kernel<LAY_K15, 15, false>), grid, block, 0, stream, a);
-    else if (a.K == 15 && layout == LAY_K15_SIGN_BYTES) hipLaunchKernelGGL((chainback_spec_kernel<LAY_K15_SIGN_BYTES, 15, false>), grid, block, 0, stream, a);
-    else if (a.K == 24 && layout == LAY_NATURAL) hipLaunchKernelGGL((chainback_spec_kernel<LAY_NATURAL, 24, true>), grid, block, 0, stream, a);
-    else if (a.K == 24 && layout == LAY_K24F) hipLaunchKernelGGL((chainback_spec_kernel<LAY_K24F, 24, true>), grid, block, 0, stream, a);
-    else if (a.K == 24 && layout == LAY_K24T) hipLaunchKernelGGL((chainback_spec_kernel<LAY_K24T, 24, true>), grid, block, 0, stream, a);
+    if (a.K == 15 && layout == LAY_NATURAL) launch_spec<LAY_NATURAL, 15, false>(a, stream);
+    else if (a.K == 15 && layout == LAY_K15) launch_spec<LAY_K15, 15, false>(a, stream);
+    else if (a.K == 15 && layout == LAY_K15_SIGN_BYTES) launch_spec<LAY_K15_SIGN_BYTES, 15, false>(a, stream);
+    else if (a.K == 24 && layout == LAY_NATURAL) launch_spec<LAY_NATURAL, 24, true>(a, stream);
+    else if (a.K == 24 && layout == LAY_K24F) launch_spec<LAY_K24F, 24, true>(a, stream);
+    else if (a.K == 24 && layout == LAY_K24T) launch_spec<LAY_K24T, 24, true>(a, stream);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

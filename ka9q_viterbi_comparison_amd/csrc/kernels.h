@@ -114,6 +114,10 @@ struct ChainbackRowsArgs {
     int K;
     int k224;                  // chainback_viterbi224_sse2 semantics (no tail skip, emits state&1)
     int k15_sign_bytes = 0;    // acs_k15 rows in the ka9q615 bit order (k15_layout.h)
+    // chainback_spec.hip, segment-parallel form (few frames): nseg > 1 segments of seg_bits decoded bits (a multiple of 8) per
+    // frame, each warmed up over seg_ovl rows; seg_scratch: (2 + 2 * nseg) * nframes words, the first 2 * nframes zero before the first launch
+    int nseg = 0, seg_bits = 0, seg_ovl = 0;
+    unsigned *seg_scratch = nullptr;
 };
 hipError_t launch_chainback_rows(const ChainbackRowsArgs &a, hipStream_t stream);
 

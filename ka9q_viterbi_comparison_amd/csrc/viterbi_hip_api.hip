@@ -72,6 +72,11 @@ struct vhip_decoder {
     size_t syms_stage_bytes = 0;
     unsigned char *d_data_stage = nullptr;
     size_t data_stage_bytes = 0;
+    unsigned *d_cbseg = nullptr;      // segment-parallel chainback (K >= 15, few frames): ticket / register words, one region per slot
+    size_t cbseg_words = 0;           //   words per region
+    int cbseg_bits = -1, cbseg_ovl = -1;  // vhip_set_chainback_segments (-1: per-code default)
+    int cbseg_last_nseg = 0;              // geometry of the last segment-parallel chainback (vhip_chainback_rewalked)
+    unsigned *cbseg_last = nullptr;
     unsigned char *d_ring = nullptr;  // K=15 fused windowed decode: decision rings of the resident workgroups
     size_t ring_bytes = 0;
     int pos = 0;
@@ -206,6 +211,40 @@ int ensure_history(vhip_decoder *p) {
     if (e != hipSuccess) return fail("decision history memset", e);
     p->total_bytes += dec_bytes;
     if (p->depth > 1) p->slots[p->cur_slot].d_dec = p->d_dec;
+    return 0;
+}
+
+// Segment-parallel speculative chainback (chainback_spec.hip) for K >= 15 when the handle holds few frames: the walk of one
+// frame is a chain of DRAM round trips, so it is cut into segments walked by separate waves and verified afterwards.
+// vhip_set_chainback_segments overrides the geometry (tests force a warm-up of 0 rows so that every segment is walked twice).
+int setup_segments(vhip_decoder *p, vh::ChainbackRowsArgs &a) {
+    // defaults measured with tools/chainback_segments_probe.py (one 2048-bit frame, K=24 at 4 dB / K=15 at 1 dB): 64-bit segments
+    // with 128 warm-up rows never needed a second walk and were fastest; 160 rows leave a margin, and a segment whose guess has
+    // not merged costs one extra 64-row walk (about 10 round trips), not correctness
+    const int seg_bits = p->cbseg_bits >= 0 ? (p->cbseg_bits & ~7) : 64;
+    const int seg_ovl = p->cbseg_ovl >= 0 ? p->cbseg_ovl : 160;
+    p->cbseg_last_nseg = 0;
+    if (seg_bits <= 0 || p->nframes > 64) return 0;  // many frames: one wave per frame already fills the memory system
+    const int nseg = (int)((a.nbits + (unsigned)seg_bits - 1) / (unsigned)seg_bits);
+    if (nseg <= 1) return 0;
+    const size_t words = (size_t)p->nframes * (size_t)(2 + 2 * nseg);
+    if (p->cbseg_words < words) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        for (int i = 0; i < p->depth && p->depth > 1; i++) HIP_TRY(hipStreamSynchronize(p->slots[i].stream));
+        if (p->d_cbseg) (void)hipFree(p->d_cbseg);
+        p->d_cbseg = nullptr;
+        p->cbseg_words = 0;
+        const size_t cap = words * 2;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cbseg), cap * sizeof(unsigned) * vhip_decoder::MAX_DEPTH));
+        HIP_TRY(hipMemset(p->d_cbseg, 0, cap * sizeof(unsigned) * vhip_decoder::MAX_DEPTH));
+        p->cbseg_words = cap;
+    }
+    a.nseg = nseg;
+    a.seg_bits = seg_bits;
+    a.seg_ovl = seg_ovl;
+    a.seg_scratch = p->d_cbseg + (size_t)(p->depth > 1 ? p->cur_slot : 0) * p->cbseg_words;
+    p->cbseg_last_nseg = nseg;
+    p->cbseg_last = a.seg_scratch;
     return 0;
 }
 
@@ -623,6 +662,7 @@ void vhip_delete(vhip_decoder *p) {
     for (auto &pr : p->t_upd) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto &pr : p->t_cb) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (p->d_flags) (void)hipFree(p->d_flags);
+    if (p->d_cbseg) (void)hipFree(p->d_cbseg);
     for (int w = 0; w < vhip_decoder::K24_WORKERS; w++)
         if (p->aux_stream[w]) (void)hipStreamDestroy(p->aux_stream[w]);
     if (p->h_report) (void)hipHostFree(p->h_report);
@@ -903,7 +943,10 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
         a.K = p->K;
         a.k224 = 1;
         if (getenv("VHIP_CHAINBACK_SIMPLE")) HIP_TRY(vh::launch_chainback_k24f(a, tiled, p->stream));
-        else HIP_TRY(vh::launch_chainback_spec(tiled ? vh::CB_LAY_K24T : vh::CB_LAY_K24F, a, p->stream));
+        else {
+            if (setup_segments(p, a) != 0) return -1;
+            HIP_TRY(vh::launch_chainback_spec(tiled ? vh::CB_LAY_K24T : vh::CB_LAY_K24F, a, p->stream));
+        }
         return 0;
     }
     if (p->variant == VHIP_VARIANT_REGS && p->K == 15) {
@@ -920,7 +963,10 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
         a.k224 = 0;
         a.k15_sign_bytes = p->code == VHIP_KA9Q615;
         if (getenv("VHIP_CHAINBACK_SIMPLE")) HIP_TRY(vh::launch_chainback_k15(a, p->run_stream()));
-        else HIP_TRY(vh::launch_chainback_spec(a.k15_sign_bytes ? vh::CB_LAY_K15_SIGN_BYTES : vh::CB_LAY_K15, a, p->run_stream()));
+        else {
+            if (setup_segments(p, a) != 0) return -1;
+            HIP_TRY(vh::launch_chainback_spec(a.k15_sign_bytes ? vh::CB_LAY_K15_SIGN_BYTES : vh::CB_LAY_K15, a, p->run_stream()));
+        }
         return 0;
     }
     if (p->variant == VHIP_VARIANT_REGS) {
@@ -949,9 +995,31 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
     a.endstate = endstate;
     a.K = p->K;
     a.k224 = (p->code == VHIP_KA9Q224);
-    if (p->K >= 15 && !getenv("VHIP_CHAINBACK_SIMPLE")) HIP_TRY(vh::launch_chainback_spec(vh::CB_LAY_NATURAL, a, p->run_stream()));
-    else HIP_TRY(vh::launch_chainback_rows(a, p->run_stream()));
+    if (p->K >= 15 && !getenv("VHIP_CHAINBACK_SIMPLE")) {
+        if (setup_segments(p, a) != 0) return -1;
+        HIP_TRY(vh::launch_chainback_spec(vh::CB_LAY_NATURAL, a, p->run_stream()));
+    } else HIP_TRY(vh::launch_chainback_rows(a, p->run_stream()));
     return 0;
+}
+
+int vhip_set_chainback_segments(vhip_decoder *p, int seg_bits, int warmup_rows) {
+    if (!p) return fail("set_chainback_segments: NULL handle");
+    if (seg_bits > 0 && (seg_bits & 7)) return fail("set_chainback_segments: seg_bits must be a multiple of 8 (0 = one walk per frame, < 0 = default)");
+    p->cbseg_bits = seg_bits;
+    p->cbseg_ovl = warmup_rows;
+    return 0;
+}
+
+int vhip_chainback_rewalked(vhip_decoder *p, int *nseg) {
+    if (!p) return fail("chainback_rewalked: NULL handle");
+    if (nseg) *nseg = p->cbseg_last_nseg;
+    if (p->cbseg_last_nseg == 0) return 0;
+    if (use_device(p) != 0 || sync_all(p) != 0) return -1;
+    std::vector<unsigned> w((size_t)p->nframes * 2);  // [frame][ticket, re-walked]
+    HIP_TRY(hipMemcpy(w.data(), p->cbseg_last, w.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    int total = 0;
+    for (int f = 0; f < p->nframes; f++) total += (int)w[(size_t)f * 2 + 1];
+    return total;
 }
 
 // ---------------------------------------------------------------- fused sliding-window decode

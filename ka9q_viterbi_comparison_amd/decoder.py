@@ -69,6 +69,17 @@ class HipViterbi:
         """Pipelined handles: order everything in flight before what the caller enqueues next on the handle's stream."""
         _lib.check(self._lib.vhip_join(self._h), "vhip_join")
 
+    def set_chainback_segments(self, seg_bits=-1, warmup_rows=-1):
+        """Geometry of the segment-parallel chainback (K >= 15, <= 64 frames); 0 = one walk per frame, < 0 = defaults."""
+        _lib.check(self._lib.vhip_set_chainback_segments(self._h, seg_bits, warmup_rows), "vhip_set_chainback_segments")
+
+    def chainback_rewalked(self):
+        """(segments walked twice, segments per frame) of the last chainback; (0, 0) if it ran as one walk."""
+        n = C.c_int(0)
+        r = self._lib.vhip_chainback_rewalked(self._h, C.byref(n))
+        _lib.check(min(r, 0), "vhip_chainback_rewalked")
+        return r, n.value
+
     def enable_timing(self, on=True):
         _lib.check(self._lib.vhip_enable_timing(self._h, int(on)), "vhip_enable_timing")
 

@@ -600,3 +600,55 @@ def test_chainback_fuzz(seed):
     for o in oracles.values():
         o.close()
     dec.close()
+
+
+@pytest.mark.parametrize("name,variant,nframes,B", [
+    ("224", VARIANT_HBM_TILED, 2, 56), ("224", VARIANT_HBM_FUSED, 1, 56), ("224", VARIANT_HBM, 1, 30),
+    ("615", VARIANT_REGS, 3, 100), ("615", VARIANT_LDS, 2, 100), ("spiral615", VARIANT_REGS, 3, 101), ("spiral615", VARIANT_LDS, 2, 101),
+])
+def test_segment_parallel_chainback(name, variant, nframes, B):
+    """The K >= 15 traceback cut into segments walked by separate waves from guessed states and verified afterwards
+    (chainback_spec.hip) gives the bytes of the one-walk chainback for every geometry -- including a warm-up of 0 rows, where
+    every guess is wrong and each segment is walked a second time from the true state -- for end states != 0 and ragged bit
+    counts (viterbi615_sse2.cpp:65-91, viterbi224_sse2.cpp:79-121)."""
+    spec = C.CODES[name]
+    code = spec.code
+    steps = B * 8 + spec.K - 1
+    payload, syms = frames(code, 4242, nframes, B, spec.ebn0_db)
+    dec = HipViterbi(name, steps, nframes=nframes, variant=variant)
+    dec.reset()
+    dec.update(syms)
+    N = 1 << (spec.K - 1)
+    oracles = []
+    for f in range(nframes):
+        o = OracleDecoder(code, spec.poly, steps)
+        o.update(syms[f], steps)
+        oracles.append(o)
+    full = steps if spec.K == 24 else B * 8
+    for nbits, end in ((full, 0), (full - 5, 3), (full, N - 2), (203, 0)):
+        want = [o.chainback(nbits, end) for o in oracles]
+        for seg_bits, warm in ((-1, -1), (64, 0), (8, 40), (128, 100000), (96, 64), (0, 0)):
+            dec.set_chainback_segments(seg_bits, warm)
+            data, rc = dec.chainback(nbits, endstate=end)
+            rew, nseg = dec.chainback_rewalked()
+            for f in range(nframes):
+                assert np.array_equal(data[f], want[f][0]), f"{name} nbits {nbits} end {end} seg {seg_bits}/{warm} frame {f}"
+            if nframes == 1:
+                assert rc == want[0][1]
+            if seg_bits == 0:
+                assert nseg == 0
+            if seg_bits == 64:
+                assert nseg == (nbits + 63) // 64
+            if seg_bits == 64 and warm == 0 and nbits > 200:
+                assert rew >= nframes, "a guessed all-zero state cannot match the true one on a noisy frame in every segment"
+            if seg_bits == 128 and nbits == full:
+                assert rew == 0, "warm-up reaching the end of the frame starts from the caller's end state: exact"
+    dec.set_chainback_segments(-1, -1)
+    data, _ = dec.chainback(full)
+    rew, nseg = dec.chainback_rewalked()
+    assert nseg >= 2
+    for f in range(nframes):
+        assert bit_errors(data[f][:B], payload[f]) == 0 or spec.K == 15
+    for o in oracles:
+        o.close()
+    dec.close()
