@@ -65,9 +65,12 @@ __global__ __launch_bounds__(256) void acs_k24_step_kernel(const int16_t *__rest
         outw[e] = ((unsigned)v0 & 0xffffu) | ((unsigned)v1 << 16);
         dbits |= (d0 << (2 * e)) | (d1 << (2 * e + 1));
     }
-    uint4 *dst = reinterpret_cast<uint4 *>(newm + 2u * j0);
-    dst[0] = make_uint4(outw[0], outw[1], outw[2], outw[3]);
-    dst[1] = make_uint4(outw[4], outw[5], outw[6], outw[7]);
+    // non-temporal: the dirty lines of a plain store would be written back once more when the kernel ends (acs_k24t.hip)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 *dst = reinterpret_cast<u32x4 *>(newm + 2u * j0);
+    const u32x4 o0 = {outw[0], outw[1], outw[2], outw[3]}, o1 = {outw[4], outw[5], outw[6], outw[7]};
+    __builtin_nontemporal_store(o0, dst);
+    __builtin_nontemporal_store(o1, dst + 1);
     reinterpret_cast<unsigned short *>(row)[gid] = (unsigned short)dbits;
     if (gid == 0) {
         const int new0 = (int)(int16_t)(outw[0] & 0xffffu);
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void acs_k24_step_kernel(const int16_t *__rest
     }
 }
 
-__global__ __launch_bounds__(256) void k24_min_kernel(const int16_t *__restrict__ m, int *__restrict__ flags) {
+__global__ __launch_bounds__(256) void k24_min_kernel(const int16_t *__restrict__ m, int *__restrict__ slot) {
     int mn = 32767;
     const uint4 *p = reinterpret_cast<const uint4 *>(m);
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < N24 / 8; i += gridDim.x * blockDim.x) {
@@ -95,11 +98,11 @@ __global__ __launch_bounds__(256) void k24_min_kernel(const int16_t *__restrict_
     __shared__ int wmin[4];
     if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = mn;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMin(&flags[K24F_MIN], min(min(wmin[0], wmin[1]), min(wmin[2], wmin[3])));
+    if (threadIdx.x == 0) atomicMin(slot, min(min(wmin[0], wmin[1]), min(wmin[2], wmin[3])));
 }
 
-__global__ __launch_bounds__(256) void k24_sub_kernel(int16_t *__restrict__ m, const int *__restrict__ flags) {
-    const int adjust = flags[K24F_MIN] + 32768;  // min - SHRT_MIN              viterbi224_sse2.cpp:240
+__global__ __launch_bounds__(256) void k24_sub_kernel(int16_t *__restrict__ m, const int *__restrict__ slot) {
+    const int adjust = *slot + 32768;  // min - SHRT_MIN              viterbi224_sse2.cpp:240
     uint4 *p = reinterpret_cast<uint4 *>(m);
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < N24 / 8; i += gridDim.x * blockDim.x) {
         uint4 v = p[i];
@@ -114,9 +117,11 @@ __global__ __launch_bounds__(256) void k24_sub_kernel(int16_t *__restrict__ m, c
     }
 }
 
-__global__ void k24_flags_reset_kernel(int *flags) {
+// reset_slot < 0: the pending flag and all three minimum slots (start of a decode); else the flag and that slot
+__global__ void k24_flags_reset_kernel(int *flags, int reset_slot) {
     flags[K24F_PENDING] = 0;
-    flags[K24F_MIN] = 0x7fffffff;
+    for (int s = 0; s < 3; s++)
+        if (reset_slot < 0 || reset_slot == s) flags[K24F_MIN + s] = 0x7fffffff;
 }
 
 hipError_t launch_k24_step(const int16_t *oldm, int16_t *newm, unsigned char *row, const unsigned char *d_syms, int step,
@@ -126,15 +131,15 @@ hipError_t launch_k24_step(const int16_t *oldm, int16_t *newm, unsigned char *ro
     return hipGetLastError();
 }
 
-hipError_t launch_k24_renorm(int16_t *m, int *flags, hipStream_t stream) {
-    hipLaunchKernelGGL(k24_min_kernel, dim3(1024), dim3(256), 0, stream, m, flags);
-    hipLaunchKernelGGL(k24_sub_kernel, dim3(2048), dim3(256), 0, stream, m, flags);
-    hipLaunchKernelGGL(k24_flags_reset_kernel, dim3(1), dim3(1), 0, stream, flags);
+hipError_t launch_k24_renorm(int16_t *m, int *flags, hipStream_t stream, int min_slot, int reset_slot) {
+    hipLaunchKernelGGL(k24_min_kernel, dim3(1024), dim3(256), 0, stream, m, flags + K24F_MIN + min_slot);
+    hipLaunchKernelGGL(k24_sub_kernel, dim3(2048), dim3(256), 0, stream, m, flags + K24F_MIN + min_slot);
+    hipLaunchKernelGGL(k24_flags_reset_kernel, dim3(1), dim3(1), 0, stream, flags, reset_slot);
     return hipGetLastError();
 }
 
 hipError_t launch_k24_flags_reset(int *flags, hipStream_t stream) {
-    hipLaunchKernelGGL(k24_flags_reset_kernel, dim3(1), dim3(1), 0, stream, flags);
+    hipLaunchKernelGGL(k24_flags_reset_kernel, dim3(1), dim3(1), 0, stream, flags, -1);
     return hipGetLastError();
 }
 

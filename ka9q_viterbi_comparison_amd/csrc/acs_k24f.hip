@@ -34,6 +34,8 @@ namespace vh {
 namespace k24f {
 
 typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int K = 24, NB = 23;
@@ -273,15 +275,20 @@ __global__ __launch_bounds__(256) void acs_k24f_pass_kernel(const int16_t *oldm,
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const unsigned gv = i * 64 + lane;
-            dst[gv] = tw[(gv & ~15u) | ((gv ^ (gv >> 4)) & 15u)];
+            // non-temporal: the dirty lines of a plain store would be written back once more when the kernel ends (acs_k24t.hip)
+            const uint4 t4 = tw[(gv & ~15u) | ((gv ^ (gv >> 4)) & 15u)];
+            const u32x4 v4 = {t4.x, t4.y, t4.z, t4.w};
+            __builtin_nontemporal_store(v4, reinterpret_cast<u32x4 *>(dst) + gv);
         }
     } else {
 #pragma unroll
         for (int v = 0; v < 16; v++) {
-            if constexpr (group_vw(G) == 4)
-                *reinterpret_cast<uint2 *>(newm + (pt | ((unsigned)v << BS))) = make_uint2(as_u32(M[2 * v]), as_u32(M[2 * v + 1]));
-            else
-                *reinterpret_cast<unsigned *>(newm + (pt | ((unsigned)v << BS))) = as_u32(M[v]);
+            if constexpr (group_vw(G) == 4) {
+                const u32x2 v2 = {as_u32(M[2 * v]), as_u32(M[2 * v + 1])};
+                __builtin_nontemporal_store(v2, reinterpret_cast<u32x2 *>(newm + (pt | ((unsigned)v << BS))));
+            } else {
+                __builtin_nontemporal_store(as_u32(M[v]), reinterpret_cast<unsigned *>(newm + (pt | ((unsigned)v << BS))));
+            }
         }
     }
 }

@@ -206,14 +206,70 @@ __device__ __forceinline__ void load_symbols(const unsigned char *syms, int s_lo
 // their parity so that such a pair lands in different halves of the 64 banks.
 __device__ __forceinline__ unsigned h_row(unsigned row) { return row ^ ((row >> 4) & 1u); }
 
-template <bool FULL, int MODE>
+// NT: bit 0 = metric loads, bit 1 = metric stores carry the non-temporal hint.  Stores: a pass writes its 16 MiB of metrics
+// in one burst at its very end, and with plain (write-back) stores the dirty lines are still in the L2s when the kernel ends,
+// so the end-of-kernel write-back -- which the next pass has to wait for -- pays for them again: 3.95 -> 3.39 ms per 2071-step
+// frame with the hint.  Loads: no difference (kept as a switch, VHIP_K24T_NT, for the record).
+template <class T>
+__device__ __forceinline__ T ld_metric(const T *p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// Renormalisation folded into the passes (viterbi224_sse2.cpp:226-246: when new[0] >= 25000 the minimum over all metrics,
+// minus SHRT_MIN, is subtracted from every metric).  The host replays the pass that raised the flag up to the flagged row;
+// that replay also forms the minimum of its final metrics (per workgroup, one atomicMin each) and the NEXT pass subtracts it
+// while it loads -- no separate min / subtract kernels, no host synchronisation.  `ctl` (0 for an ordinary pass; only the
+// FULL = false instantiations look at it):
+//   bits 1..0  1 + slot that receives this pass's minimum            (the replay of the raising pass)
+//   bits 3..2  1 + slot whose minimum is subtracted at load          (the first pass behind a renormalised row)
+//   bits 5..4  1 + slot to reset to "no minimum yet"                 (slots rotate 0,1,2: the pass that applies event n's
+//                                                                     minimum clears the slot event n+2 will use)
+//   bit  6     clear the pending flag at the end                     (the replay: younger cancelled passes are behind it)
+enum { K24T_CTL_MIN = 0, K24T_CTL_ADJ = 2, K24T_CTL_RESET = 4, K24T_CTL_CLEAR = 64 };
+__device__ __forceinline__ void ctl_apply_adjust(i16x2 (&M)[32], const int *flags, int ctl) {
+    const int slot = ((ctl >> K24T_CTL_ADJ) & 3) - 1;
+    if (slot >= 0) {
+        const unsigned short adj = (unsigned short)(flags[K24F_MIN + slot] + 32768);  // min - SHRT_MIN          :240
+        const u16x2 av = {adj, adj};
+#pragma unroll
+        for (int q = 0; q < 32; q++) M[q] = (i16x2)((u16x2)M[q] - av);                 // sub_epi16 wraps         :245-246
+    }
+}
+template <int NWAVES>
+__device__ __forceinline__ void ctl_finish(const i16x2 (&M)[32], int *flags, int ctl, unsigned tile, unsigned tid, int *wmin) {
+    const int mslot = ((ctl >> K24T_CTL_MIN) & 3) - 1;
+    if (mslot >= 0) {
+        i16x2 mn = M[0];
+#pragma unroll
+        for (int q = 1; q < 32; q++) mn = __builtin_elementwise_min(mn, M[q]);
+        int m = min((int)mn.x, (int)mn.y);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = min(m, __shfl_xor(m, off));
+        if ((tid & 63u) == 0) wmin[tid >> 6] = m;
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int w = 1; w < NWAVES; w++) m = min(m, wmin[w]);
+            atomicMin(&flags[K24F_MIN + mslot], m);
+        }
+    }
+    if (tile == 0 && tid == 0) {
+        const int rslot = ((ctl >> K24T_CTL_RESET) & 3) - 1;
+        if (rslot >= 0) flags[K24F_MIN + rslot] = 0x7fffffff;
+        if (ctl & K24T_CTL_CLEAR) flags[K24F_PENDING] = 0;
+    }
+}
+
+template <bool FULL, int MODE, int NT = 2>
 __device__ __forceinline__ void pass_h_body(const int16_t *oldm, int16_t *__restrict__ newm, unsigned char *__restrict__ rows,
-                                            const unsigned char *syms, int rel_row0, int s_lo, int s_hi, int *__restrict__ flags,
-                                            K24Report mirror) {
+                                            const unsigned char *syms, int rel_row0, int s_lo, int s_hi, int *flags,
+                                            K24Report mirror, int ctl) {
     // rows/syms point at the row of the pass's first phase; rel_row0 = that row's index in the call
     int pending = flags[K24F_PENDING];  // looked at below, behind the metric loads
     const SignMasks sm;
     __shared__ unsigned img[512 * 32];
+    __shared__ int wmin[8];
     const unsigned tile = blockIdx.x, tid = threadIdx.x;
     unsigned sy[9];
     load_symbols<9, FULL>(syms, s_lo, s_hi, sy);
@@ -221,12 +277,13 @@ __device__ __forceinline__ void pass_h_body(const int16_t *oldm, int16_t *__rest
     {
         const unsigned pt = k24t_thread_base(K24T_H1, tile, tid);
 #pragma unroll
-        for (int q = 0; q < 32; q++) M[q] = MODE == 2 ? as_v(pt + q) : as_v(*reinterpret_cast<const unsigned *>(oldm + (pt | ((unsigned)q << 18))));
+        for (int q = 0; q < 32; q++) M[q] = MODE == 2 ? as_v(pt + q) : as_v(ld_metric(reinterpret_cast<const unsigned *>(oldm + (pt | ((unsigned)q << 18))), NT & 1));
         asm volatile("" : "+s"(pending) : : "memory");  // the flag (a dependent scalar load) is examined behind the loads
         if (pending != 0 && pending - 1 < rel_row0 + s_lo) {
             if (tile == 0 && tid == 0) k24_report(mirror, pending);
             return;
         }
+        if constexpr (!FULL) ctl_apply_adjust(M, flags, ctl);
         run_group<K24T_H1, 0, FULL, MODE>(M, sy, pt, tile, tid, rows, rel_row0, s_lo, s_hi, flags, pending, sm);
         // regroup: row = bits 22..14 = (q << 4) | t4, dword = t5
         const unsigned t4 = tid >> 5, t5 = tid & 31u;
@@ -247,10 +304,18 @@ __device__ __forceinline__ void pass_h_body(const int16_t *oldm, int16_t *__rest
         }
         run_group<K24T_H2, 0, FULL, MODE>(M, sy, pt, tile, tid, rows, rel_row0, s_lo, s_hi, flags, pending, sm);
         if (tile == 0 && tid == 0) k24_report(mirror, pending);  // the last pass of a host batch reports the flag
+        if constexpr (!FULL) ctl_finish<8>(M, flags, ctl, tile, tid, wmin);
 #pragma unroll
         for (int v = 0; v < 16; v++)
-            if (MODE != 2 || as_u32(M[2 * v]) == 0x12345u)
-                *reinterpret_cast<uint2 *>(newm + (pt | ((unsigned)v << 14))) = make_uint2(as_u32(M[2 * v]), as_u32(M[2 * v + 1]));
+            if (MODE != 2 || as_u32(M[2 * v]) == 0x12345u) {
+                unsigned *dst = reinterpret_cast<unsigned *>(newm + (pt | ((unsigned)v << 14)));
+                if constexpr (NT & 2) {
+                    const u32x2 val = {as_u32(M[2 * v]), as_u32(M[2 * v + 1])};
+                    __builtin_nontemporal_store(val, reinterpret_cast<u32x2 *>(dst));
+                } else {
+                    *reinterpret_cast<uint2 *>(dst) = make_uint2(as_u32(M[2 * v]), as_u32(M[2 * v + 1]));
+                }
+            }
     }
 }
 
@@ -261,19 +326,20 @@ __device__ __forceinline__ void pass_h_body(const int16_t *oldm, int16_t *__rest
 // 2..0 alone, so L3's 16-byte reads stay aligned quads.
 __device__ __forceinline__ unsigned l_swz(unsigned d) { return d ^ (((d >> 8) & 31u) << 3); }
 
-template <bool FULL, int MODE>
+template <bool FULL, int MODE, int NT = 2>
 __global__ __launch_bounds__(512) void acs_k24t_pass_h_kernel(const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,
-                                                              int rel_row0, int s_lo, int s_hi, int *flags, K24Report mirror) {
-    pass_h_body<FULL, MODE>(oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);
+                                                              int rel_row0, int s_lo, int s_hi, int *flags, K24Report mirror, int ctl) {
+    pass_h_body<FULL, MODE, NT>(oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, ctl);
 }
 
-template <bool FULL, int MODE>
+template <bool FULL, int MODE, int NT = 2>
 __device__ __forceinline__ void pass_l_body(const int16_t *oldm, int16_t *__restrict__ newm, unsigned char *__restrict__ rows,
-                                            const unsigned char *syms, int rel_row0, int s_lo, int s_hi, int *__restrict__ flags,
-                                            K24Report mirror) {
+                                            const unsigned char *syms, int rel_row0, int s_lo, int s_hi, int *flags,
+                                            K24Report mirror, int ctl) {
     int pending = flags[K24F_PENDING];
     const SignMasks sm;
     __shared__ __attribute__((aligned(16))) unsigned img[8192];
+    __shared__ int wmin[4];
     const unsigned tile = blockIdx.x, tid = threadIdx.x;
     unsigned sy[14];
     load_symbols<14, FULL>(syms, s_lo, s_hi, sy);
@@ -281,12 +347,13 @@ __device__ __forceinline__ void pass_l_body(const int16_t *oldm, int16_t *__rest
     {
         const unsigned pt = k24t_thread_base(K24T_L1, tile, tid);
 #pragma unroll
-        for (int q = 0; q < 32; q++) M[q] = MODE == 2 ? as_v(pt + q) : as_v(*reinterpret_cast<const unsigned *>(oldm + (pt | ((unsigned)q << 9))));
+        for (int q = 0; q < 32; q++) M[q] = MODE == 2 ? as_v(pt + q) : as_v(ld_metric(reinterpret_cast<const unsigned *>(oldm + (pt | ((unsigned)q << 9))), NT & 1));
         asm volatile("" : "+s"(pending) : : "memory");
         if (pending != 0 && pending - 1 < rel_row0 + s_lo) {
             if (tile == 0 && tid == 0) k24_report(mirror, pending);
             return;
         }
+        if constexpr (!FULL) ctl_apply_adjust(M, flags, ctl);
         run_group<K24T_L1, 9, FULL, MODE>(M, sy, pt, tile, tid, rows, rel_row0, s_lo, s_hi, flags, pending, sm);
         if constexpr (MODE != 3)
 #pragma unroll
@@ -319,21 +386,30 @@ __device__ __forceinline__ void pass_l_body(const int16_t *oldm, int16_t *__rest
         }
         run_group<K24T_L3, 9, FULL, MODE>(M, sy, pt, tile, tid, rows, rel_row0, s_lo, s_hi, flags, pending, sm);
         if (tile == 0 && tid == 0) k24_report(mirror, pending);
+        if constexpr (!FULL) ctl_finish<4>(M, flags, ctl, tile, tid, wmin);
 #pragma unroll
         for (int q2 = 0; q2 < 4; q2++) {
             if (MODE != 2 || as_u32(M[8 * q2]) == 0x12345u) {
-                uint4 *dst = reinterpret_cast<uint4 *>(newm + (pt | ((unsigned)q2 << 12)));
-                dst[0] = make_uint4(as_u32(M[8 * q2 + 0]), as_u32(M[8 * q2 + 1]), as_u32(M[8 * q2 + 2]), as_u32(M[8 * q2 + 3]));
-                dst[1] = make_uint4(as_u32(M[8 * q2 + 4]), as_u32(M[8 * q2 + 5]), as_u32(M[8 * q2 + 6]), as_u32(M[8 * q2 + 7]));
+                if constexpr (NT & 2) {
+                    u32x4 *dst = reinterpret_cast<u32x4 *>(newm + (pt | ((unsigned)q2 << 12)));
+                    const u32x4 v0 = {as_u32(M[8 * q2 + 0]), as_u32(M[8 * q2 + 1]), as_u32(M[8 * q2 + 2]), as_u32(M[8 * q2 + 3])};
+                    const u32x4 v1 = {as_u32(M[8 * q2 + 4]), as_u32(M[8 * q2 + 5]), as_u32(M[8 * q2 + 6]), as_u32(M[8 * q2 + 7])};
+                    __builtin_nontemporal_store(v0, dst);
+                    __builtin_nontemporal_store(v1, dst + 1);
+                } else {
+                    uint4 *dst = reinterpret_cast<uint4 *>(newm + (pt | ((unsigned)q2 << 12)));
+                    dst[0] = make_uint4(as_u32(M[8 * q2 + 0]), as_u32(M[8 * q2 + 1]), as_u32(M[8 * q2 + 2]), as_u32(M[8 * q2 + 3]));
+                    dst[1] = make_uint4(as_u32(M[8 * q2 + 4]), as_u32(M[8 * q2 + 5]), as_u32(M[8 * q2 + 6]), as_u32(M[8 * q2 + 7]));
+                }
             }
         }
     }
 }
 
-template <bool FULL, int MODE>
+template <bool FULL, int MODE, int NT = 2>
 __global__ __launch_bounds__(256, 2) void acs_k24t_pass_l_kernel(const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,
-                                                                 int rel_row0, int s_lo, int s_hi, int *flags, K24Report mirror) {
-    pass_l_body<FULL, MODE>(oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);
+                                                                 int rel_row0, int s_lo, int s_hi, int *flags, K24Report mirror, int ctl) {
+    pass_l_body<FULL, MODE, NT>(oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, ctl);
 }
 
 }  // namespace k24t
@@ -343,17 +419,17 @@ bool k24t_poly_supported(const int *poly) { return poly[0] == k24t::POLY[0] && p
 
 // one pass: stages [s_lo, s_hi) of pass `pass` (0 = H: phases 0..8, 1 = L: phases 9..22); rows/syms are those of the pass's
 // first phase
-template <int MODE>
+template <int MODE, int NT = 2>
 static hipError_t launch_pass_mode(int pass, const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,
-                                   int rel_row0, int s_lo, int s_hi, int *flags, K24Report mirror, hipStream_t stream) {
+                                   int rel_row0, int s_lo, int s_hi, int *flags, K24Report mirror, hipStream_t stream, int ctl) {
     if (pass == 0) {
-        const bool full = s_lo == 0 && s_hi == 9;
-        if (full) hipLaunchKernelGGL((k24t::acs_k24t_pass_h_kernel<true, MODE>), dim3(256), dim3(512), 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);
-        else hipLaunchKernelGGL((k24t::acs_k24t_pass_h_kernel<false, MODE>), dim3(256), dim3(512), 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);
+        const bool full = s_lo == 0 && s_hi == 9 && ctl == 0;
+        if (full) hipLaunchKernelGGL((k24t::acs_k24t_pass_h_kernel<true, MODE, NT>), dim3(256), dim3(512), 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, ctl);
+        else hipLaunchKernelGGL((k24t::acs_k24t_pass_h_kernel<false, MODE, NT>), dim3(256), dim3(512), 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, ctl);
     } else if (pass == 1) {
-        const bool full = s_lo == 0 && s_hi == 14;
-        if (full) hipLaunchKernelGGL((k24t::acs_k24t_pass_l_kernel<true, MODE>), dim3(512), dim3(256), 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);
-        else hipLaunchKernelGGL((k24t::acs_k24t_pass_l_kernel<false, MODE>), dim3(512), dim3(256), 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);
+        const bool full = s_lo == 0 && s_hi == 14 && ctl == 0;
+        if (full) hipLaunchKernelGGL((k24t::acs_k24t_pass_l_kernel<true, MODE, NT>), dim3(512), dim3(256), 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, ctl);
+        else hipLaunchKernelGGL((k24t::acs_k24t_pass_l_kernel<false, MODE, NT>), dim3(512), dim3(256), 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, ctl);
     } else {
         return hipErrorInvalidValue;
     }
@@ -361,12 +437,16 @@ static hipError_t launch_pass_mode(int pass, const int16_t *oldm, int16_t *newm,
 }
 
 hipError_t launch_k24t_pass(int pass, const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,
-                            int rel_row0, int s_lo, int s_hi, int *flags, K24Report mirror, hipStream_t stream) {
+                            int rel_row0, int s_lo, int s_hi, int *flags, K24Report mirror, hipStream_t stream, bool nt_stores, int ctl) {
     static const int mode = getenv("VHIP_K24T_MODE") ? atoi(getenv("VHIP_K24T_MODE")) : 0;  // timing experiments only
-    if (mode == 1) return launch_pass_mode<1>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream);
-    if (mode == 3) return launch_pass_mode<3>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream);
-    if (mode == 2) return launch_pass_mode<2>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream);
-    return launch_pass_mode<0>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream);
+    if (mode == 1) return launch_pass_mode<1>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
+    if (mode == 3) return launch_pass_mode<3>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
+    if (mode == 2) return launch_pass_mode<2>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
+    static const int nt_env = getenv("VHIP_K24T_NT") ? atoi(getenv("VHIP_K24T_NT")) : -1;  // A/B switch for the non-temporal hints
+    const int nt = nt_env >= 0 ? nt_env : (nt_stores ? 2 : 0);
+    if (nt == 0) return launch_pass_mode<0, 0>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
+    if (nt == 3) return launch_pass_mode<0, 3>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
+    return launch_pass_mode<0>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
 }
 
 #endif  // !VH_JIT_KERNEL
@@ -376,8 +456,8 @@ hipError_t launch_k24t_pass(int pass, const int16_t *oldm, int16_t *newm, unsign
 #ifdef VH_JIT_KERNEL
 #define VH_JIT_PASS(NAME, BODY, FULL, BOUNDS)                                                                                    \
     extern "C" __global__ BOUNDS void NAME(const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,  \
-                                           int rel_row0, int s_lo, int s_hi, int *flags, vh::K24Report mirror) {                 \
-        vh::k24t::BODY<FULL, 0>(oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror);                                    \
+                                           int rel_row0, int s_lo, int s_hi, int *flags, vh::K24Report mirror, int ctl) {        \
+        vh::k24t::BODY<FULL, 0, 2>(oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, ctl);                            \
     }
 VH_JIT_PASS(vh_jit_k24t_h_full, pass_h_body, true, __launch_bounds__(512))
 VH_JIT_PASS(vh_jit_k24t_h_part, pass_h_body, false, __launch_bounds__(512))

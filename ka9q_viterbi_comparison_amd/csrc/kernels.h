@@ -122,7 +122,7 @@ struct ChainbackRowsArgs {
 hipError_t launch_chainback_rows(const ChainbackRowsArgs &a, hipStream_t stream);
 
 // ---------------------------------------------------------------- acs_k24.hip (K = 24, metrics in HBM)
-enum { K24F_PENDING = 0, K24F_MIN = 1, K24F_COUNT = 4 };  // device flag words
+enum { K24F_PENDING = 0, K24F_MIN = 1, K24F_COUNT = 4 };  // device flag words: pending row + 1, three rotating minimum slots
 // Progress word of the multi-step K=24 passes, in pinned host memory: every pass stores (seq << 32) | pending flag when its
 // flag-owning thread is done, so the host follows the stream by polling one word instead of waiting on events (an event
 // record / wait per batch of passes put a ~8 us bubble into the stream each time).
@@ -137,7 +137,8 @@ __device__ __forceinline__ void k24_report(const K24Report &r, int pending) {
 #endif
 hipError_t launch_k24_step(const int16_t *oldm, int16_t *newm, unsigned char *row, const unsigned char *d_syms, int step,
                            const int *poly, int *flags, hipStream_t stream);
-hipError_t launch_k24_renorm(int16_t *m, int *flags, hipStream_t stream);  // min-reduce, subtract, clear flags
+// min-reduce into slot min_slot, subtract, clear the pending flag and slot reset_slot
+hipError_t launch_k24_renorm(int16_t *m, int *flags, hipStream_t stream, int min_slot = 0, int reset_slot = 0);
 hipError_t launch_k24_flags_reset(int *flags, hipStream_t stream);
 
 // ---------------------------------------------------------------- acs_k24f.hip (K = 24, 4/7 steps per pass)
@@ -149,7 +150,8 @@ hipError_t launch_chainback_k24f(const ChainbackRowsArgs &a, bool tiled, hipStre
 // ---------------------------------------------------------------- acs_k24t.hip (K = 24, two passes per 23 steps)
 bool k24t_poly_supported(const int *poly);
 hipError_t launch_k24t_pass(int pass, const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,
-                            int rel_row0, int s_lo, int s_hi, int *flags, K24Report mirror, hipStream_t stream);
+                            int rel_row0, int s_lo, int s_hi, int *flags, K24Report mirror, hipStream_t stream, bool nt_stores,
+                            int ctl);  // ctl: renormalisation duties of this pass (acs_k24t.hip), 0 for an ordinary pass
 
 // ---------------------------------------------------------------- jit.hip (fast kernels for other polynomials)
 bool jit_enabled();  // VHIP_JIT=0 turns the runtime specialisation off

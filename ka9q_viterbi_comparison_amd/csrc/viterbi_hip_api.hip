@@ -89,6 +89,7 @@ struct vhip_decoder {
     unsigned long long *h_report = nullptr;          // K=24: pinned progress words (kernels.h K24Report), one per stream
     unsigned long long *h_report_dev = nullptr;      //        the same words as the device addresses them
     unsigned k24_seq[1 + K24_WORKERS] = {};          //        last sequence number handed out per stream
+    unsigned k24_events[1 + K24_WORKERS] = {};       //        renormalisation events since the flag words of that stream were reset
     size_t total_bytes = 0;
     // Pipelined decodes (vhip_set_pipeline_depth): `depth` sets of {decision history, metrics, internal stream}.
     // d_dec / d_metrics / pos above always describe the CURRENT set; vhip_init() rotates to the next one.
@@ -115,6 +116,11 @@ struct vhip_decoder {
 };
 
 namespace {
+
+// K=24 tiled passes: non-temporal metric stores help a lone decode (the next pass does not wait for an end-of-kernel write-back
+// of 16 MiB of dirty lines: 3.95 -> 3.39 ms per 2071-step frame) and cost 7 % when three decodes share the chip (12 frames on
+// one handle: 1.92 -> 2.07 ms per frame), where the write-back is hidden behind the other decodes' passes.
+constexpr int K24_WORKERS_MIN_PLAIN = 3;
 
 // vhip_status(): -1 after a failed init / update / chainback on the handle, 0 after a successful one.  The reference ABI
 // returns void from update and a path metric (any int) from chainback_viterbi615, so the return value alone cannot
@@ -375,7 +381,7 @@ bool k24_multistep(int variant) { return variant == VHIP_VARIANT_HBM_FUSED || va
 // the progress word and returns, so ONE host thread keeps several frames in flight on several streams (vhip_update_dev
 // with nframes > 1) -- no helper threads.
 struct K24Run {
-    struct Pass { int g, s_lo, s_hi, rel, in; unsigned seq; };  // rel = index in this call of the row of stage s_lo
+    struct Pass { int g, s_lo, s_hi, rel, in; unsigned seq; int ctl; };  // rel = index in this call of the row of stage s_lo; ctl: acs_k24t.hip
     vhip_decoder *p = nullptr;
     int f = -1, steps = 0, row0 = 0, slot = 0;
     const unsigned char *d_syms = nullptr;
@@ -388,6 +394,7 @@ struct K24Run {
     size_t depth = 6;
     std::deque<Pass> inflight;
     unsigned spins = 0;
+    int next_ctl = 0;  // tiled passes: renormalisation duties of the next pass to be enqueued (subtract a minimum while loading)
 
     void start(vhip_decoder *h, int frame, const unsigned char *syms, int nsteps, int first_row, hipStream_t st, int *fl) {
         p = h; f = frame; d_syms = syms; steps = nsteps; row0 = first_row; stream = st; flags = fl;
@@ -404,6 +411,7 @@ struct K24Run {
         depth = tiled ? 6 : 12;
         inflight.clear();
         spins = 0;
+        next_ctl = 0;
     }
     int group_of(int phi, int &first, int &np) const {
         if (tiled) {
@@ -427,12 +435,14 @@ struct K24Run {
             int rel0 = q.rel - q.s_lo, s_lo = q.s_lo, s_hi = q.s_hi;
             int *fl = flags;
             vh::K24Report rp = rep;
-            void *args[] = {&oldm, &newm, &rw, &sy, &rel0, &s_lo, &s_hi, &fl, &rp};
-            const bool full = s_lo == 0 && s_hi == vh::k24t_pass_nphases(q.g);
+            int ctl = q.ctl;
+            void *args[] = {&oldm, &newm, &rw, &sy, &rel0, &s_lo, &s_hi, &fl, &rp, &ctl};
+            const bool full = s_lo == 0 && s_hi == vh::k24t_pass_nphases(q.g) && ctl == 0;
             HIP_TRY(hipModuleLaunchKernel(p->jit_fn[q.g * 2 + (full ? 0 : 1)], q.g == 0 ? 256 : 512, 1, 1, q.g == 0 ? 512 : 256, 1, 1, 0, stream, args, nullptr));
         } else if (tiled) {
             HIP_TRY(vh::launch_k24t_pass(q.g, buf[q.in], buf[q.in ^ 1], rows + row_g0 * (long)p->row_bytes,
-                                         d_syms + ((long)q.rel - q.s_lo) * 2, q.rel - q.s_lo, q.s_lo, q.s_hi, flags, rep, stream));
+                                         d_syms + ((long)q.rel - q.s_lo) * 2, q.rel - q.s_lo, q.s_lo, q.s_hi, flags, rep, stream,
+                                         p->nframes < K24_WORKERS_MIN_PLAIN, q.ctl));
         } else {
             HIP_TRY(vh::launch_k24f_pass(q.g, buf[q.in], buf[q.in ^ 1], rows + row_g0 * (long)p->row_bytes,
                                          d_syms + ((long)q.rel - q.s_lo) * 2, q.rel - q.s_lo, q.s_lo, q.s_hi, flags, rep, stream));
@@ -452,7 +462,8 @@ struct K24Run {
                 const int phi = (row0 + tt) % 23;
                 int first, np;
                 const int g = group_of(phi, first, np);
-                Pass ps{g, phi - first, std::min(np, phi - first + (steps - tt)), tt, c, ++seq};
+                Pass ps{g, phi - first, std::min(np, phi - first + (steps - tt)), tt, c, ++seq, next_ctl};
+                next_ctl = 0;
                 if (launch(ps, true) != 0) return -1;
                 inflight.push_back(ps);
                 tt += ps.s_hi - ps.s_lo;
@@ -480,14 +491,32 @@ struct K24Run {
             }
             const int rr = pending - 1;  // renormalise after this row of the call
             if (rr < front.rel) return fail("K=24: renormalisation flag out of range");
-            HIP_TRY(hipStreamSynchronize(stream));  // the younger passes have returned at once
-            HIP_TRY(vh::launch_k24_flags_reset(flags, stream));
             Pass redo = front;
             redo.s_hi = redo.s_lo + (rr - redo.rel) + 1;  // replay the raising pass up to and including row rr
             redo.seq = ++seq;
-            if (launch(redo, false) != 0) return -1;
-            cur = redo.in ^ 1;
-            HIP_TRY(vh::launch_k24_renorm(buf[cur], flags, stream));  // min-reduce, wrapping subtract, clear flags
+            if (tiled && rr + 1 < steps) {
+                // Tiled passes renormalise among themselves (acs_k24t.hip ctl): the replay forms the minimum of its final
+                // metrics in slot n % 3 and clears the flag when it is done -- it is enqueued behind the younger passes, which
+                // have seen the flag and return at once, so nothing has to be waited for here --, and the next pass enqueued
+                // subtracts that minimum while it loads and clears the slot event n + 2 will use.  A pass that raises the flag
+                // again keeps its own subtract duty when it is replayed.
+                const unsigned n = p->k24_events[slot]++;
+                redo.ctl = (front.ctl & ~(3 | 64)) | (1 + (int)(n % 3)) | 64;
+                if (launch(redo, false) != 0) return -1;
+                next_ctl = ((1 + (int)(n % 3)) << 2) | ((1 + (int)((n + 2) % 3)) << 4);
+                cur = redo.in ^ 1;
+            } else {
+                // the k24f passes, or a renormalisation behind the last row of this call (no pass left to subtract the
+                // minimum): separate min / subtract kernels
+                HIP_TRY(hipStreamSynchronize(stream));  // the younger passes have returned at once
+                const unsigned n = tiled ? p->k24_events[slot]++ : 0u;
+                if (!tiled) HIP_TRY(vh::launch_k24_flags_reset(flags, stream));
+                redo.ctl = tiled ? (front.ctl & ~(3 | 64)) : 0;
+                if (launch(redo, false) != 0) return -1;
+                cur = redo.in ^ 1;
+                // min-reduce, wrapping subtract, clear the flag (and, tiled, the slot event n + 2 will use)
+                HIP_TRY(vh::launch_k24_renorm(buf[cur], flags, stream, (int)(n % 3), tiled ? (int)((n + 2) % 3) : 0));
+            }
             t = rr + 1;
             tt = t;
             c = cur;
@@ -510,7 +539,10 @@ int k24f_update_frames(vhip_decoder *p, const unsigned char *d_syms, size_t sym_
     K24Run runs[W];
     bool active[W] = {};
     int next = 0, live = 0;
-    for (int w = 0; w < W; w++) HIP_TRY(vh::launch_k24_flags_reset(p->d_flags + 4 * (w + 1), p->aux_stream[w]));
+    for (int w = 0; w < W; w++) {
+        HIP_TRY(vh::launch_k24_flags_reset(p->d_flags + 4 * (w + 1), p->aux_stream[w]));
+        p->k24_events[w + 1] = 0;
+    }
     while (next < p->nframes || live > 0) {
         bool progressed = false;
         for (int w = 0; w < W; w++) {
@@ -827,6 +859,7 @@ int vhip_init(vhip_decoder *p, int starting_state) {
             p->k24_cur[f] = 0;
         }
         HIP_TRY(vh::launch_k24_flags_reset(p->d_flags, p->stream));
+        p->k24_events[0] = 0;
     } else {
         HIP_TRY(vh::launch_init_metrics(p->d_metrics, p->N, p->nframes, ia, is, start, p->run_stream()));
     }

@@ -231,6 +231,44 @@ def test_k24_renormalisation_and_incremental(variant):
     dec.close()
 
 
+def test_k24_renormalisation_at_call_boundaries():
+    """The tiled K=24 passes renormalise among themselves: the replay of the pass that raised the flag forms the minimum and
+    the next pass subtracts it while it loads (acs_k24t.hip ctl).  The row after which viterbi224_sse2.cpp:226-246
+    renormalises is located with the oracle, and update calls are cut so that the renormalisation falls behind the LAST row
+    of a call (no pass left in that call: the separate min / subtract kernels run), one row before the end of a call (the
+    subtracting pass is a single row) and at the first row of a call."""
+    code = C.KA9Q224
+    spec = spec_of(code)
+    B = 56
+    steps = B * 8 + spec.K - 1
+    _, syms = frames(code, 11, 1, B, spec.ebn0_db)
+    s2 = syms.reshape(1, steps, spec.R)
+    o = OracleDecoder(code, spec.poly, steps)
+    rstar = None
+    for r in range(steps):
+        o.update(s2[0, r].reshape(-1), 1)
+        if o.renorms >= 1:
+            rstar = r
+            break
+    assert rstar is not None and 25 < rstar < steps - 30
+    o.update(s2[0, rstar + 1:].reshape(-1), steps - rstar - 1)
+    want_metrics, want_rows = o.metrics(), o.rows(steps)
+    want_data, _ = o.chainback(steps, 0)
+    o.close()
+    for variant in (VARIANT_HBM_TILED, VARIANT_HBM_FUSED):
+        for first in (rstar + 1, rstar + 2, rstar, rstar - 1, rstar + 1 - 23):
+            dec = HipViterbi("224", steps, variant=variant)
+            dec.reset()
+            dec.update(np.ascontiguousarray(s2[:, :first, :]), nbits=first)
+            dec.update(np.ascontiguousarray(s2[:, first:, :]), nbits=steps - first)
+            data, _ = dec.chainback(steps)
+            assert np.array_equal(dec.metrics(0), want_metrics), f"variant {variant}: metrics, first call {first} rows (renormalisation after row {rstar})"
+            for r in (rstar - 1, rstar, rstar + 1, rstar + 2, rstar + 24, steps - 1):
+                assert np.array_equal(dec.decision_rows(0, r, 1), want_rows[r:r + 1]), f"variant {variant} first {first} row {r}"
+            assert np.array_equal(data[0], want_data)
+            dec.close()
+
+
 def test_k24_many_frames_per_handle():
     """Seven K=24 frames on one handle: with VARIANT_HBM_FUSED each of the three in-flight decode slots takes several
     frames in turn, every one through a renormalisation (viterbi224_sse2.cpp:226-246) and its speculative replay.
