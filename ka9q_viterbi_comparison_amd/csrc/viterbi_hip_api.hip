@@ -260,12 +260,16 @@ int sync_all(vhip_decoder *p) {
     return 0;
 }
 
-// lanes per frame for the REGS kernels: the smallest L that still puts a wave on (most of) the 1024 SIMDs.  Fewer
-// lanes per frame means fewer duplicated branch-metric instructions and fewer half/lane stages; measured on 65536
-// K=7 frames: L=1 0.92 ms, L=2 1.10 ms, L=4 1.31 ms.
+// lanes per frame for the REGS kernels.  K=7: the smallest L that still puts a wave on (most of) the 1024 SIMDs -- fewer
+// lanes per frame means fewer duplicated branch-metric instructions and fewer half/lane stages; measured on 65536 K=7
+// frames: L=1 0.92 ms, L=2 1.10 ms, L=4 1.31 ms.  K=9 (128 packed registers per frame): always four lanes, i.e. the same
+// 32 metric registers per lane as K=7 with one -- 64 or 128 registers per lane leave hipcc no room to interleave butterflies;
+// decode rate on a double-buffered handle, L = 1 / 2 / 4 (tools/lb_sweep.sh, profiles/r02_lanes_per_frame.txt): K=9 r=1/2
+// 32768 frames 60.7 / 57.8 / 66.8 Gsym/s, 131072 frames 62.0 / 58.3 / 67.2; r=1/4 101.5 / 96.4 / 103.3 and 103.7 / 97.2 / 102.9.
 int auto_regs_lb(int code, int nframes) {
     int lb = 0;
     while (lb < 2 && (long)nframes * (1 << lb) < 64L * 768) lb++;
+    if (vhip_code_K(code) == 9) lb = 2;
     while (!vh::regs_lanes_supported(code, lb) && lb < 2) lb++;
     if (const char *e = getenv("VHIP_REGS_LB")) {
         const int v = atoi(e);
