@@ -681,6 +681,8 @@ def test_segment_parallel_chainback(name, variant, nframes, B):
                 assert rew >= nframes, "a guessed all-zero state cannot match the true one on a noisy frame in every segment"
             if seg_bits == 128 and nbits == full:
                 assert rew == 0, "warm-up reaching the end of the frame starts from the caller's end state: exact"
+    with pytest.raises(Exception):
+        dec.set_chainback_segments(12, 0)  # not a multiple of 8
     dec.set_chainback_segments(-1, -1)
     data, _ = dec.chainback(full)
     rew, nseg = dec.chainback_rewalked()
