@@ -429,9 +429,7 @@ __device__ __forceinline__ void acs_k15_body(const Args &a) {
                         u16x2 mn = (u16x2)M[0];
 #pragma unroll
                         for (int i = 1; i < NR; i++) mn = __builtin_elementwise_min(mn, (u16x2)M[i]);
-                        unsigned m = min((unsigned)mn.x, (unsigned)mn.y);
-#pragma unroll
-                        for (int o = 32; o >= 1; o >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, o));
+                        const unsigned m = wave_min(min((unsigned)mn.x, (unsigned)mn.y));
                         if ((tid & 63u) == 0) sm.red[2 * (r & 1) + (tid >> 6)] = (int)m;
                         if (tid == 0) sm.flag[r & 1] = (as_u32(M[0]) & 0xffffu) > ((74u << 8) | 0xffu);
                         __syncthreads();
@@ -449,9 +447,7 @@ __device__ __forceinline__ void acs_k15_body(const Args &a) {
                         i16x2 mn = M[0];
 #pragma unroll
                         for (int i = 1; i < NR; i++) mn = __builtin_elementwise_min(mn, M[i]);
-                        int m = min((int)mn.x, (int)mn.y);
-#pragma unroll
-                        for (int o = 32; o >= 1; o >>= 1) m = min(m, __shfl_xor(m, o));
+                        int m = wave_min(min((int)mn.x, (int)mn.y));
                         if ((tid & 63u) == 0) sm.red[tid >> 6] = m;
                         __syncthreads();
                         m = min(sm.red[0], sm.red[1]);

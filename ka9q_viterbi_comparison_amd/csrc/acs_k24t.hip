@@ -243,9 +243,7 @@ __device__ __forceinline__ void ctl_finish(const i16x2 (&M)[32], int *flags, int
         i16x2 mn = M[0];
 #pragma unroll
         for (int q = 1; q < 32; q++) mn = __builtin_elementwise_min(mn, M[q]);
-        int m = min((int)mn.x, (int)mn.y);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) m = min(m, __shfl_xor(m, off));
+        int m = wave_min(min((int)mn.x, (int)mn.y));
         if ((tid & 63u) == 0) wmin[tid >> 6] = m;
         __syncthreads();
         if (tid == 0) {

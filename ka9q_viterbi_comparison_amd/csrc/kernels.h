@@ -22,6 +22,22 @@ __device__ __forceinline__ unsigned sgpr_const() {
     return V;
 #endif
 }
+// Minimum over the 64 lanes of a wave with six DPP steps (quad_perm x2, row_half_mirror, row_mirror, row_bcast:15, row_bcast:31;
+// the result lands in lane 63 and is read back as a scalar).  __shfl_xor compiles to ds_bpermute_b32: six dependent LDS round
+// trips, which the spiral615 kernel paid on EVERY trellis step.
+template <class T>
+__device__ __forceinline__ T wave_min(T v) {
+    static_assert(sizeof(T) == 4, "32-bit values");
+#define VH_DPP_MIN(ctrl, rmask) v = min(v, (T)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false))
+    VH_DPP_MIN(0xB1, 0xf);   // quad_perm [1,0,3,2]
+    VH_DPP_MIN(0x4E, 0xf);   // quad_perm [2,3,0,1]
+    VH_DPP_MIN(0x141, 0xf);  // row_half_mirror
+    VH_DPP_MIN(0x140, 0xf);  // row_mirror: every lane of a row of 16 holds the row's minimum
+    VH_DPP_MIN(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    VH_DPP_MIN(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef VH_DPP_MIN
+    return (T)__builtin_amdgcn_readlane((int)v, 63);
+}
 // the eight sign-byte masks 0x80808080 >> i used by the K=15 / K=24 decision gather (put_signs)
 struct SignMasks {
     unsigned m[8];
