@@ -274,8 +274,13 @@ __device__ __forceinline__ void pass_h_body(const int16_t *oldm, int16_t *__rest
     i16x2 M[32];
     {
         const unsigned pt = k24t_thread_base(K24T_H1, tile, tid);
+        // issue order (0, 16, 1, 17, ...): the pass's first phase pairs register q with q ^ 16, and the 16 MiB of a pass arrive
+        // over ~3 us, so its first butterflies can start on the first lines instead of waiting for the last
 #pragma unroll
-        for (int q = 0; q < 32; q++) M[q] = MODE == 2 ? as_v(pt + q) : as_v(ld_metric(reinterpret_cast<const unsigned *>(oldm + (pt | ((unsigned)q << 18))), NT & 1));
+        for (int i = 0; i < 32; i++) {
+            const int q = (i >> 1) | ((i & 1) << 4);
+            M[q] = MODE == 2 ? as_v(pt + q) : as_v(ld_metric(reinterpret_cast<const unsigned *>(oldm + (pt | ((unsigned)q << 18))), NT & 1));
+        }
         asm volatile("" : "+s"(pending) : : "memory");  // the flag (a dependent scalar load) is examined behind the loads
         if (pending != 0 && pending - 1 < rel_row0 + s_lo) {
             if (tile == 0 && tid == 0) k24_report(mirror, pending);
@@ -345,7 +350,10 @@ __device__ __forceinline__ void pass_l_body(const int16_t *oldm, int16_t *__rest
     {
         const unsigned pt = k24t_thread_base(K24T_L1, tile, tid);
 #pragma unroll
-        for (int q = 0; q < 32; q++) M[q] = MODE == 2 ? as_v(pt + q) : as_v(ld_metric(reinterpret_cast<const unsigned *>(oldm + (pt | ((unsigned)q << 9))), NT & 1));
+        for (int i = 0; i < 32; i++) {  // issue order (0, 16, 1, 17, ...), as in pass H
+            const int q = (i >> 1) | ((i & 1) << 4);
+            M[q] = MODE == 2 ? as_v(pt + q) : as_v(ld_metric(reinterpret_cast<const unsigned *>(oldm + (pt | ((unsigned)q << 9))), NT & 1));
+        }
         asm volatile("" : "+s"(pending) : : "memory");
         if (pending != 0 && pending - 1 < rel_row0 + s_lo) {
             if (tile == 0 && tid == 0) k24_report(mirror, pending);
