@@ -164,7 +164,7 @@ __device__ __forceinline__ void stage(i16x2 (&M)[k24t_nr(G)], unsigned s0, unsig
 // The stages [s_lo, s_hi) of the PASS (0-based inside the pass) that belong to group G, run on M.  PF = first phase of the pass.
 // MODE (timing experiments only, tools/k24t_probe.sh; results are wrong unless MODE == 0): 1 = data movement only (loads,
 // LDS regrouping, stores; no trellis stages), 2 = no global metric loads / stores (stages and row stores only), 3 = global
-// loads and stores only
+// loads and stores only, 4 = as 2 without the decision-row stores, 5 = as 2 without the LDS regrouping traffic
 template <int G, int PF, bool FULL, int MODE, int NSY>
 __device__ __forceinline__ void run_group(i16x2 (&M)[k24t_nr(G)], const unsigned (&sy)[NSY], unsigned pt, unsigned tile, unsigned tid,
                                           unsigned char *__restrict__ rows, int rel_row0, int s_lo, int s_hi, int *__restrict__ flags,
@@ -180,8 +180,10 @@ __device__ __forceinline__ void run_group(i16x2 (&M)[k24t_nr(G)], const unsigned
             unsigned *row = reinterpret_cast<unsigned *>(rows + (size_t)S * (N / 8)) + ((size_t)tile * k24t_threads(G) + tid) * WPT;
             // written once, read by the chainback much later: keep the rows out of the caches the metrics live in
             static_assert(WPT == 2, "two words per thread and row");
-            __builtin_nontemporal_store(acc[0], row);
-            __builtin_nontemporal_store(acc[1], row + 1);
+            if (MODE != 4 || (acc[0] ^ acc[1]) == 0x12345u) {
+                __builtin_nontemporal_store(acc[0], row);
+                __builtin_nontemporal_store(acc[1], row + 1);
+            }
             if (MODE == 0 && tile == 0 && tid == 0) {  // state 0 is position 0 in every phase: tile 0, thread 0, register 0, low field
                 const int new0 = (int)(short)(as_u32(M[0]) & 0xffffu);
                 if (new0 >= Code224::renorm_thr && pending == 0) flags[K24F_PENDING] = pending = rel_row0 + S + 1;
@@ -279,7 +281,7 @@ __device__ __forceinline__ void pass_h_body(const int16_t *oldm, int16_t *__rest
 #pragma unroll
         for (int i = 0; i < 32; i++) {
             const int q = (i >> 1) | ((i & 1) << 4);
-            M[q] = MODE == 2 ? as_v(pt + q) : as_v(ld_metric(reinterpret_cast<const unsigned *>(oldm + (pt | ((unsigned)q << 18))), NT & 1));
+            M[q] = (MODE == 2 || MODE == 4 || MODE == 5) ? as_v(pt + q) : as_v(ld_metric(reinterpret_cast<const unsigned *>(oldm + (pt | ((unsigned)q << 18))), NT & 1));
         }
         asm volatile("" : "+s"(pending) : : "memory");  // the flag (a dependent scalar load) is examined behind the loads
         if (pending != 0 && pending - 1 < rel_row0 + s_lo) {
@@ -290,7 +292,7 @@ __device__ __forceinline__ void pass_h_body(const int16_t *oldm, int16_t *__rest
         run_group<K24T_H1, 0, FULL, MODE>(M, sy, pt, tile, tid, rows, rel_row0, s_lo, s_hi, flags, pending, sm);
         // regroup: row = bits 22..14 = (q << 4) | t4, dword = t5
         const unsigned t4 = tid >> 5, t5 = tid & 31u;
-        if constexpr (MODE != 3)
+        if constexpr (MODE != 3 && MODE != 5)
 #pragma unroll
         for (int q = 0; q < 32; q++) img[h_row(((unsigned)q << 4) | t4) * 32 + t5] = as_u32(M[q]);
     }
@@ -298,7 +300,7 @@ __device__ __forceinline__ void pass_h_body(const int16_t *oldm, int16_t *__rest
     {
         const unsigned pt = k24t_thread_base(K24T_H2, tile, tid);
         const unsigned t5 = tid >> 4, t4 = tid & 15u;
-        if constexpr (MODE != 3)
+        if constexpr (MODE != 3 && MODE != 5)
 #pragma unroll
         for (int v = 0; v < 16; v++) {
             const uint2 d = *reinterpret_cast<const uint2 *>(&img[h_row((t5 << 4) | (unsigned)v) * 32 + 2 * t4]);
@@ -310,7 +312,7 @@ __device__ __forceinline__ void pass_h_body(const int16_t *oldm, int16_t *__rest
         if constexpr (!FULL) ctl_finish<8>(M, flags, ctl, tile, tid, wmin);
 #pragma unroll
         for (int v = 0; v < 16; v++)
-            if (MODE != 2 || as_u32(M[2 * v]) == 0x12345u) {
+            if ((MODE != 2 && MODE != 4 && MODE != 5) || as_u32(M[2 * v]) == 0x12345u) {
                 unsigned *dst = reinterpret_cast<unsigned *>(newm + (pt | ((unsigned)v << 14)));
                 if constexpr (NT & 2) {
                     const u32x2 val = {as_u32(M[2 * v]), as_u32(M[2 * v + 1])};
@@ -352,7 +354,7 @@ __device__ __forceinline__ void pass_l_body(const int16_t *oldm, int16_t *__rest
 #pragma unroll
         for (int i = 0; i < 32; i++) {  // issue order (0, 16, 1, 17, ...), as in pass H
             const int q = (i >> 1) | ((i & 1) << 4);
-            M[q] = MODE == 2 ? as_v(pt + q) : as_v(ld_metric(reinterpret_cast<const unsigned *>(oldm + (pt | ((unsigned)q << 9))), NT & 1));
+            M[q] = (MODE == 2 || MODE == 4 || MODE == 5) ? as_v(pt + q) : as_v(ld_metric(reinterpret_cast<const unsigned *>(oldm + (pt | ((unsigned)q << 9))), NT & 1));
         }
         asm volatile("" : "+s"(pending) : : "memory");
         if (pending != 0 && pending - 1 < rel_row0 + s_lo) {
@@ -361,7 +363,7 @@ __device__ __forceinline__ void pass_l_body(const int16_t *oldm, int16_t *__rest
         }
         if constexpr (!FULL) ctl_apply_adjust(M, flags, ctl);
         run_group<K24T_L1, 9, FULL, MODE>(M, sy, pt, tile, tid, rows, rel_row0, s_lo, s_hi, flags, pending, sm);
-        if constexpr (MODE != 3)
+        if constexpr (MODE != 3 && MODE != 5)
 #pragma unroll
         for (int q = 0; q < 32; q++) img[l_swz(((unsigned)q << 8) | tid)] = as_u32(M[q]);
     }
@@ -369,12 +371,12 @@ __device__ __forceinline__ void pass_l_body(const int16_t *oldm, int16_t *__rest
     {
         const unsigned pt = k24t_thread_base(K24T_L2, tile, tid);
         const unsigned t5 = tid >> 3, t3 = tid & 7u;
-        if constexpr (MODE != 3)
+        if constexpr (MODE != 3 && MODE != 5)
 #pragma unroll
         for (int q = 0; q < 32; q++) M[q] = as_v(img[l_swz((t5 << 8) | ((unsigned)q << 3) | t3)]);
         run_group<K24T_L2, 9, FULL, MODE>(M, sy, pt, tile, tid, rows, rel_row0, s_lo, s_hi, flags, pending, sm);
         // every thread writes back exactly the dwords it read: no barrier needed in front of these stores
-        if constexpr (MODE != 3)
+        if constexpr (MODE != 3 && MODE != 5)
 #pragma unroll
         for (int q = 0; q < 32; q++) img[l_swz((t5 << 8) | ((unsigned)q << 3) | t3)] = as_u32(M[q]);
     }
@@ -382,7 +384,7 @@ __device__ __forceinline__ void pass_l_body(const int16_t *oldm, int16_t *__rest
     {
         // thread = position bits 11..4; registers: rho = (q2 << 3) | k3 holds positions (q2 << 12) | (tid << 4) | (k3 << 1) | field
         const unsigned pt = k24t_thread_base(K24T_L3, tile, tid);
-        if constexpr (MODE != 3)
+        if constexpr (MODE != 3 && MODE != 5)
 #pragma unroll
         for (int q2 = 0; q2 < 4; q2++) {
             const unsigned d = l_swz(((unsigned)q2 << 11) | (tid << 3));
@@ -395,7 +397,7 @@ __device__ __forceinline__ void pass_l_body(const int16_t *oldm, int16_t *__rest
         if constexpr (!FULL) ctl_finish<4>(M, flags, ctl, tile, tid, wmin);
 #pragma unroll
         for (int q2 = 0; q2 < 4; q2++) {
-            if (MODE != 2 || as_u32(M[8 * q2]) == 0x12345u) {
+            if ((MODE != 2 && MODE != 4 && MODE != 5) || as_u32(M[8 * q2]) == 0x12345u) {
                 if constexpr (NT & 2) {
                     u32x4 *dst = reinterpret_cast<u32x4 *>(newm + (pt | ((unsigned)q2 << 12)));
                     const u32x4 v0 = {as_u32(M[8 * q2 + 0]), as_u32(M[8 * q2 + 1]), as_u32(M[8 * q2 + 2]), as_u32(M[8 * q2 + 3])};
@@ -448,6 +450,8 @@ hipError_t launch_k24t_pass(int pass, const int16_t *oldm, int16_t *newm, unsign
     if (mode == 1) return launch_pass_mode<1>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
     if (mode == 3) return launch_pass_mode<3>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
     if (mode == 2) return launch_pass_mode<2>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
+    if (mode == 4) return launch_pass_mode<4>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
+    if (mode == 5) return launch_pass_mode<5>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
     static const int nt_env = getenv("VHIP_K24T_NT") ? atoi(getenv("VHIP_K24T_NT")) : -1;  // A/B switch for the non-temporal hints
     const int nt = nt_env >= 0 ? nt_env : (nt_stores ? 2 : 0);
     if (nt == 0) return launch_pass_mode<0, 0>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);

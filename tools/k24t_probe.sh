@@ -1,6 +1,6 @@
 #!/bin/bash
 # Where does a K=24 tiled pass spend its time?  Kernel trace of bench.py --code 224 in the three timing modes of
-# acs_k24t.hip (VHIP_K24T_MODE: 0 = real, 1 = data movement only, 2 = trellis stages + row stores only; modes 1 and 2
+# acs_k24t.hip (VHIP_K24T_MODE: 0 = real, 1 = data movement only, 2 = trellis stages + row stores only, 3 = global loads + stores only, 4 = 2 without row stores, 5 = 2 without LDS regrouping; modes 1..5
 # produce wrong results by design).  Run on the GPU box from the repo root.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${1:-k24t_probe}
