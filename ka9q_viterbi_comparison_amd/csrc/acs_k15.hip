@@ -333,6 +333,10 @@ __device__ __forceinline__ void acs_k15_body(const Args &a) {
     __shared__ Smem sm;
     const SignMasks sgm;
     const unsigned tid = threadIdx.x;
+    // group-A transposes (see run_group): byte address of this lane's dword in row (tid & 1), and the v_perm_b32 selector that
+    // picks (own dword's half, partner dword's half) for an even lane / (partner's high half, own high half) for an odd one
+    const unsigned pair_addr = (tid & 1u) * (ROWP * 2) + (tid & ~1u) * 2;
+    const unsigned pair_sel = (tid & 1u) ? 0x07060302u : 0x01000504u;
   for (long f = blockIdx.x; f < (WIN ? (long)a.nframes : (long)blockIdx.x + 1); f += gridDim.x) {
     int row0, row_end, phi0;
     int16_t *gm = nullptr;
@@ -391,11 +395,16 @@ __device__ __forceinline__ void acs_k15_body(const Args &a) {
             constexpr int G = decltype(GSEL)::value;  // 0: phases 0..6 (free bits 7..13), 1: phases 7..13 (free bits 0..6)
             // gather this thread's 128 positions
             if constexpr (G == 0) {
+                // A thread of this group owns one COLUMN of the image: 128 metrics 272 bytes apart.  Reading them one by one
+                // is 128 16-bit LDS instructions, and the LDS pipe takes as long for a 16-bit wave access as for a 32-bit one
+                // (the group's two transposes were 2.2 of 16.5 ms).  Lanes t and t ^ 1 own neighbouring columns, i.e. the
+                // two halves of the same dwords: the even lane fetches the dword of row 2 r0, the odd lane that of row
+                // 2 r0 + 1, the pair swaps them with one DPP move and each lane picks its two halves with one v_perm_b32.
 #pragma unroll
                 for (int r0 = 0; r0 < NR; r0++) {
-                    const unsigned lo = (unsigned short)sm.img[(2 * r0) * ROWP + tid];
-                    const unsigned hi = (unsigned short)sm.img[(2 * r0 + 1) * ROWP + tid];
-                    M[r0] = as_v(lo | (hi << 16));
+                    const unsigned x = *reinterpret_cast<const unsigned *>(reinterpret_cast<const unsigned char *>(sm.img) + pair_addr + (2 * r0) * ROWP * 2);
+                    const unsigned px = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+                    M[r0] = as_v(__builtin_amdgcn_perm(x, px, pair_sel));
                 }
             } else {
                 const uint4 *src = reinterpret_cast<const uint4 *>(&sm.img[tid * ROWP]);
@@ -468,10 +477,13 @@ __device__ __forceinline__ void acs_k15_body(const Args &a) {
             });
             // scatter back to the position image
             if constexpr (G == 0) {
+                // the reverse: the pair swaps registers, the even lane writes the dword of row 2 r0 (its own low half, the
+                // partner's low half), the odd lane that of row 2 r0 + 1 (the partner's high half, its own)
 #pragma unroll
                 for (int r0 = 0; r0 < NR; r0++) {
-                    sm.img[(2 * r0) * ROWP + tid] = M[r0].x;
-                    sm.img[(2 * r0 + 1) * ROWP + tid] = M[r0].y;
+                    const unsigned m = as_u32(M[r0]);
+                    const unsigned pm = (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0xB1, 0xf, 0xf, true);
+                    *reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(sm.img) + pair_addr + (2 * r0) * ROWP * 2) = __builtin_amdgcn_perm(m, pm, pair_sel);
                 }
             } else {
                 uint4 *dst = reinterpret_cast<uint4 *>(&sm.img[tid * ROWP]);
