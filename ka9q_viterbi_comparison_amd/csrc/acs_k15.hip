@@ -113,22 +113,51 @@ __device__ __forceinline__ i16x2 madd(i16x2 a, unsigned t) {
     else return __builtin_elementwise_add_sat(a, as_v(t));                                                   // adds_epi16
 }
 
-// One trellis step at phase PHI on the 128 positions this thread holds.  SP selects the spiral615 arithmetic.
-template <bool SP, int PHI>
-__device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R], unsigned tid, unsigned (&words)[4], const SignMasks &sm) {
-    constexpr int b = NB - 1 - PHI;            // position bit paired in this phase
-    constexpr bool GA = b >= 7;                // group A: free bits 7..13, thread bits 0..6; group B: the reverse
-    constexpr int kf = GA ? b - 7 : b;         // local free-bit index of the paired bit (0 = the half bit)
-    constexpr int FSH = GA ? 7 : 0;            // local position q <-> position bits: p_q = q << FSH
-    constexpr int TSH = GA ? 0 : 7;            // thread bits <-> position bits:     p_t = tid << TSH
-
-    // class offset of the thread-id bits, folded into the symbols (conditional complement)
+// Branch-table class offset of this thread's thread-id bits at phase PHI (linear in GF(2); folded into the symbols as a
+// conditional complement).  It depends on the thread and the phase only.  Left to itself hipcc hoists the 14 x 6 complement
+// masks out of the step loop, runs out of registers (the kernel sits at 256 VGPRs) and spills them: every trellis step then
+// began with three scratch reloads and an s_waitcnt vmcnt(0) that also drained the previous step's decision stores.  So the 14
+// six-bit offsets are formed once per kernel, kept packed in three registers, and the masks are rebuilt on every step behind
+// an opaque asm that keeps them from being hoisted (12 VALU instructions per step).
+template <int PHI>
+__device__ __forceinline__ unsigned class_offset(unsigned tid) {
+    constexpr int b = NB - 1 - PHI;
+    constexpr int TSH = b >= 7 ? 0 : 7;  // thread bits <-> position bits: p_t = tid << TSH
     unsigned cl = 0;
     sfor<7>([&](auto I) {
         constexpr int i = decltype(I)::value;
         constexpr unsigned ci = cls(rotl14(1u << (i + TSH), PHI));
         cl ^= ((tid >> i) & 1u) ? ci : 0u;
     });
+    return cl;
+}
+struct ClassOffsets {
+    unsigned w[3];
+    __device__ __forceinline__ explicit ClassOffsets(unsigned tid) {
+        w[0] = w[1] = w[2] = 0;
+        sfor<NB>([&](auto P) {
+            constexpr int PHI = decltype(P)::value;
+            w[PHI / 5] |= class_offset<PHI>(tid) << (6 * (PHI % 5));
+        });
+    }
+    template <int PHI>
+    __device__ __forceinline__ unsigned get() const {
+        unsigned cl = (w[PHI / 5] >> (6 * (PHI % 5))) & 63u;
+        asm volatile("" : "+v"(cl));  // not loop-invariant as far as the compiler can tell
+        return cl;
+    }
+};
+
+// One trellis step at phase PHI on the 128 positions this thread holds.  SP selects the spiral615 arithmetic.
+template <bool SP, int PHI>
+__device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R], const ClassOffsets &co, unsigned (&words)[4], const SignMasks &sm) {
+    constexpr int b = NB - 1 - PHI;            // position bit paired in this phase
+    constexpr bool GA = b >= 7;                // group A: free bits 7..13, thread bits 0..6; group B: the reverse
+    constexpr int kf = GA ? b - 7 : b;         // local free-bit index of the paired bit (0 = the half bit)
+    constexpr int FSH = GA ? 7 : 0;            // local position q <-> position bits: p_q = q << FSH
+
+    // class offset of the thread-id bits, folded into the symbols (conditional complement)
+    const unsigned cl = co.template get<PHI>();
     unsigned s[R];
 #pragma unroll
     for (int r = 0; r < R; r++) s[r] = sraw[r] ^ (((cl >> r) & 1u) ? 255u : 0u);
@@ -337,6 +366,7 @@ __device__ __forceinline__ void acs_k15_body(const Args &a) {
     // picks (own dword's half, partner dword's half) for an even lane / (partner's high half, own high half) for an odd one
     const unsigned pair_addr = (tid & 1u) * (ROWP * 2) + (tid & ~1u) * 2;
     const unsigned pair_sel = (tid & 1u) ? 0x07060302u : 0x01000504u;
+    const ClassOffsets co(tid);
   for (long f = blockIdx.x; f < (WIN ? (long)a.nframes : (long)blockIdx.x + 1); f += gridDim.x) {
     int row0, row_end, phi0;
     int16_t *gm = nullptr;
@@ -400,11 +430,19 @@ __device__ __forceinline__ void acs_k15_body(const Args &a) {
                 // (the group's two transposes were 2.2 of 16.5 ms).  Lanes t and t ^ 1 own neighbouring columns, i.e. the
                 // two halves of the same dwords: the even lane fetches the dword of row 2 r0, the odd lane that of row
                 // 2 r0 + 1, the pair swaps them with one DPP move and each lane picks its two halves with one v_perm_b32.
+                // (The fused windowed decode keeps the 16-bit accesses: with its ring bookkeeping live as well the extra
+                // registers of the pair exchange cost it more than the LDS instructions saved -- 2.37 vs 2.21 Gsym/s.)
 #pragma unroll
                 for (int r0 = 0; r0 < NR; r0++) {
-                    const unsigned x = *reinterpret_cast<const unsigned *>(reinterpret_cast<const unsigned char *>(sm.img) + pair_addr + (2 * r0) * ROWP * 2);
-                    const unsigned px = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
-                    M[r0] = as_v(__builtin_amdgcn_perm(x, px, pair_sel));
+                    if constexpr (WIN) {
+                        const unsigned lo = (unsigned short)sm.img[(2 * r0) * ROWP + tid];
+                        const unsigned hi = (unsigned short)sm.img[(2 * r0 + 1) * ROWP + tid];
+                        M[r0] = as_v(lo | (hi << 16));
+                    } else {
+                        const unsigned x = *reinterpret_cast<const unsigned *>(reinterpret_cast<const unsigned char *>(sm.img) + pair_addr + (2 * r0) * ROWP * 2);
+                        const unsigned px = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+                        M[r0] = as_v(__builtin_amdgcn_perm(x, px, pair_sel));
+                    }
                 }
             } else {
                 const uint4 *src = reinterpret_cast<const uint4 *>(&sm.img[tid * ROWP]);
@@ -429,7 +467,7 @@ __device__ __forceinline__ void acs_k15_body(const Args &a) {
                         sraw[q] = (cur[idx >> 2] >> (8 * (idx & 3))) & 255u;
                     }
                     unsigned words[4];
-                    stage<SP, PHI>(M, sraw, tid, words, sgm);
+                    stage<SP, PHI>(M, sraw, co, words, sgm);
                     if constexpr (WIN) {
                         unsigned *rr = ring + (long)(r % WIN_RING) * 512 + tid;
 #pragma unroll
@@ -481,9 +519,14 @@ __device__ __forceinline__ void acs_k15_body(const Args &a) {
                 // partner's low half), the odd lane that of row 2 r0 + 1 (the partner's high half, its own)
 #pragma unroll
                 for (int r0 = 0; r0 < NR; r0++) {
-                    const unsigned m = as_u32(M[r0]);
-                    const unsigned pm = (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0xB1, 0xf, 0xf, true);
-                    *reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(sm.img) + pair_addr + (2 * r0) * ROWP * 2) = __builtin_amdgcn_perm(m, pm, pair_sel);
+                    if constexpr (WIN) {
+                        sm.img[(2 * r0) * ROWP + tid] = M[r0].x;
+                        sm.img[(2 * r0 + 1) * ROWP + tid] = M[r0].y;
+                    } else {
+                        const unsigned m = as_u32(M[r0]);
+                        const unsigned pm = (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0xB1, 0xf, 0xf, true);
+                        *reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(sm.img) + pair_addr + (2 * r0) * ROWP * 2) = __builtin_amdgcn_perm(m, pm, pair_sel);
+                    }
                 }
             } else {
                 uint4 *dst = reinterpret_cast<uint4 *>(&sm.img[tid * ROWP]);
