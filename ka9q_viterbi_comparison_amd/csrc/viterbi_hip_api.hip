@@ -242,7 +242,11 @@ int setup_segments(vhip_decoder *p, vh::ChainbackRowsArgs &a) {
         p->cbseg_words = 0;
         const size_t cap = words * 2;
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_cbseg), cap * sizeof(unsigned) * vhip_decoder::MAX_DEPTH));
+        // hipMemset may return before the fill has run, and the internal streams of a pipelined handle are non-blocking (they
+        // do not order themselves behind the null stream): wait for it, or the first chainback could find a ticket word that
+        // is cleared under its feet
         HIP_TRY(hipMemset(p->d_cbseg, 0, cap * sizeof(unsigned) * vhip_decoder::MAX_DEPTH));
+        HIP_TRY(hipStreamSynchronize(nullptr));
         p->cbseg_words = cap;
     }
     a.nseg = nseg;
@@ -648,6 +652,7 @@ vhip_decoder *vhip_create(int code, const int *poly, int len, int nframes) {
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&p->d_metrics), met_bytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_flags), sizeof(int) * 32);
     if (e == hipSuccess) e = hipMemset(p->d_flags, 0, sizeof(int) * 32);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // the fill is complete before any (possibly non-blocking) stream uses the words
     if (e != hipSuccess) {
         fail("create: device allocation", e);
         vhip_delete(p);
@@ -785,6 +790,7 @@ int vhip_set_pipeline_depth(vhip_decoder *p, int depth) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // the hipMemset fills above: the slot streams are non-blocking
     p->depth = depth;  // from here on vhip_delete releases the slots
     p->cur_slot = 0;
     if (e != hipSuccess) return fail("set_pipeline_depth: allocation", e);
