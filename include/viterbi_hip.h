@@ -20,6 +20,13 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: exactly the functions declared here are exported. */
+#if defined(__GNUC__)
+#define VHIP_API __attribute__((visibility("default")))
+#else
+#define VHIP_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -56,25 +63,25 @@ typedef struct vhip_decoder vhip_decoder;
  *    Return value: 0, or for VHIP_KA9Q615 with nframes==1 the end-state path metric
  *    (viterbi615_sse2.cpp:76,90); negative on error.
  * ------------------------------------------------------------------------------------------------ */
-vhip_decoder *vhip_create(int code, const int *poly, int len, int nframes);
-int vhip_init(vhip_decoder *p, int starting_state);
+VHIP_API vhip_decoder *vhip_create(int code, const int *poly, int len, int nframes);
+VHIP_API int vhip_init(vhip_decoder *p, int starting_state);
 /* host-pointer, blocking (copies H2D / D2H around the kernels) */
-int vhip_update(vhip_decoder *p, const unsigned char *syms, int nbits);
-int vhip_chainback(vhip_decoder *p, unsigned char *data, unsigned int nbits, unsigned int endstate);
+VHIP_API int vhip_update(vhip_decoder *p, const unsigned char *syms, int nbits);
+VHIP_API int vhip_chainback(vhip_decoder *p, unsigned char *data, unsigned int nbits, unsigned int endstate);
 /* device-pointer, asynchronous on the handle's stream (inputs already resident in HBM).
  * Exception -- VHIP_KA9Q224: vhip_update_dev BLOCKS the calling thread until the update has been enqueued to its end.  The
  * K=24 renormalisation (viterbi224_sse2.cpp:226-246) is run speculatively, several multi-step passes ahead of the device,
  * and the host has to follow the passes' progress word to commit or replay them; with nframes > 1 three frames at a time
  * are in flight on internal streams, all driven by the calling thread (no helper threads).  vhip_init and
  * vhip_chainback_dev stay asynchronous. */
-int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits);
-int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbits, unsigned int endstate);
-void vhip_delete(vhip_decoder *p);
+VHIP_API int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits);
+VHIP_API int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbits, unsigned int endstate);
+VHIP_API void vhip_delete(vhip_decoder *p);
 
 /* Error status of the last init / update / chainback on the handle: 0 = succeeded, -1 = failed (message in
  * vhip_last_error()).  The reference ABI cannot carry it: update_*_blk returns void, and chainback_viterbi615 returns
  * the end state's path metric (viterbi615_sse2.cpp:76,90), which may be any int, -1 included. */
-int vhip_status(const vhip_decoder *p);
+VHIP_API int vhip_status(const vhip_decoder *p);
 
 /* Pipelined decodes (additive).  depth = 2 (or 3) gives the handle that many {decision history, path metrics} sets and
  * internal streams; every vhip_init() starts a new decode on the next set, so init / update / chainback issued back to
@@ -84,9 +91,9 @@ int vhip_status(const vhip_decoder *p);
  * does not block) or vhip_sync().  Consecutive decodes must be given different output buffers.  depth can be set once,
  * before the first update; K=24 handles do not take it (they keep several frames in flight by themselves).
  * HBM cost: depth x the decision history (vhip_device_bytes). */
-int vhip_set_pipeline_depth(vhip_decoder *p, int depth);
-int vhip_get_pipeline_depth(const vhip_decoder *p);
-int vhip_join(vhip_decoder *p);
+VHIP_API int vhip_set_pipeline_depth(vhip_decoder *p, int depth);
+VHIP_API int vhip_get_pipeline_depth(const vhip_decoder *p);
+VHIP_API int vhip_join(vhip_decoder *p);
 
 /* Chainback of the K >= 15 codes with at most 64 frames per handle: one frame's traceback is a chain of dependent DRAM round
  * trips, so it is cut into segments of `seg_bits` decoded bits (a multiple of 8) that separate waves walk at the same time,
@@ -96,14 +103,14 @@ int vhip_join(vhip_decoder *p);
  * seg_bits = 0: one walk per frame; negative values: the defaults (64 / 160).
  * vhip_chainback_rewalked: segments the last chainback had to walk twice (summed over frames; blocks until it is done);
  * *nseg = segments per frame of that chainback, 0 if it ran as one walk. */
-int vhip_set_chainback_segments(vhip_decoder *p, int seg_bits, int warmup_rows);
-int vhip_chainback_rewalked(vhip_decoder *p, int *nseg);
+VHIP_API int vhip_set_chainback_segments(vhip_decoder *p, int seg_bits, int warmup_rows);
+VHIP_API int vhip_chainback_rewalked(vhip_decoder *p, int *nseg);
 
 /* Live kernel timing.  When enabled, every vhip_update_dev / vhip_chainback_dev is bracketed by HIP events on the stream
  * its kernels run on (the handle's stream, or the internal stream of the current pipeline slot).  vhip_read_timing waits
  * for the handle to go idle and returns the summed durations (ms) and launch counts since the previous read. */
-int vhip_enable_timing(vhip_decoder *p, int on);
-int vhip_read_timing(vhip_decoder *p, double *update_ms_sum, int *n_update, double *chainback_ms_sum, int *n_chainback);
+VHIP_API int vhip_enable_timing(vhip_decoder *p, int on);
+VHIP_API int vhip_read_timing(vhip_decoder *p, double *update_ms_sum, int *n_update, double *chainback_ms_sum, int *n_chainback);
 
 /* Fused sliding-window decode (additive): init + ACS update + traceback in ONE kernel for the K <= 9
  * and K = 15 codes with the harness polynomials.  The decisions of the last trellis steps live in a ring -- 64 rows in LDS
@@ -116,16 +123,16 @@ int vhip_read_timing(vhip_decoder *p, double *update_ms_sum, int *n_update, doub
  * covers the frame (the error rate converges on the exact path's as the depth grows: tests/test_windowed.py).  There is no
  * reference function with these semantics (the reference's decoders that take a traceback length live in its un-vendored
  * submodule, src/main.cpp:169); they are defined by oracle/viterbi_oracle.c vo_chainback_windowed. */
-int vhip_decode_windowed_dev(vhip_decoder *p, const unsigned char *d_syms, unsigned int nbits, unsigned char *d_data);
-int vhip_window_depth(const vhip_decoder *p); /* traceback depth in trellis steps, or -1 if the code has no fused decode */
-int vhip_window_block(const vhip_decoder *p); /* payload bits decoded per traceback */
+VHIP_API int vhip_decode_windowed_dev(vhip_decoder *p, const unsigned char *d_syms, unsigned int nbits, unsigned char *d_data);
+VHIP_API int vhip_window_depth(const vhip_decoder *p); /* traceback depth in trellis steps, or -1 if the code has no fused decode */
+VHIP_API int vhip_window_block(const vhip_decoder *p); /* payload bits decoded per traceback */
 
 /* Stream / device plumbing.  `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
  * NULL selects the device's default stream. */
-int vhip_set_stream(vhip_decoder *p, void *stream);
-int vhip_sync(vhip_decoder *p);
-int vhip_device_count(void);
-const char *vhip_last_error(void);
+VHIP_API int vhip_set_stream(vhip_decoder *p, void *stream);
+VHIP_API int vhip_sync(vhip_decoder *p);
+VHIP_API int vhip_device_count(void);
+VHIP_API const char *vhip_last_error(void);
 
 /* Kernel variant selection (0 = automatic).  Exposed so parity tests can pin every kernel family. */
 enum vhip_variant {
@@ -136,24 +143,24 @@ enum vhip_variant {
     VHIP_VARIANT_HBM_FUSED = 4, /* K=24: 4 or 7 trellis steps per pass over the metric array (harness polynomials) */
     VHIP_VARIANT_HBM_TILED = 5  /* K=24: 9 or 14 steps per pass -- two passes per 23 steps, tiles regrouped through LDS */
 };
-int vhip_set_variant(vhip_decoder *p, int variant);
+VHIP_API int vhip_set_variant(vhip_decoder *p, int variant);
 /* Polynomials other than the reference harness's (src/main.cpp:367-415): the fast kernels are compiled for them when the
  * handle is created (hipcc --genco on the library's own kernel sources, a few seconds, cached under $VHIP_JIT_CACHE or
  * /tmp/vhip_jit_cache_<uid>) and run at the speed of the harness polynomials; 1 = this handle runs such a build.  Without
  * the sources or hipcc next to the library, or with VHIP_JIT=0, the handle uses the slower any-polynomial kernels
  * (VHIP_VARIANT_LDS / VHIP_VARIANT_HBM) and asking for the fast variant explicitly is an error. */
-int vhip_is_runtime_specialised(const vhip_decoder *p);
-int vhip_get_variant(const vhip_decoder *p);
+VHIP_API int vhip_is_runtime_specialised(const vhip_decoder *p);
+VHIP_API int vhip_get_variant(const vhip_decoder *p);
 
 /* Introspection for parity tests (blocking): natural decision bitmap rows (bit n of a row = new state n,
  * 2^(K-1)/8 bytes per row) and current path metrics in natural units widened to int32. */
-int vhip_read_decision_rows(vhip_decoder *p, int frame, int row0, int nrows, unsigned char *out);
-int vhip_read_metrics(vhip_decoder *p, int frame, int32_t *out);
-int vhip_rows_written(const vhip_decoder *p);
-int vhip_code_K(int code);
-int vhip_code_R(int code);
+VHIP_API int vhip_read_decision_rows(vhip_decoder *p, int frame, int row0, int nrows, unsigned char *out);
+VHIP_API int vhip_read_metrics(vhip_decoder *p, int frame, int32_t *out);
+VHIP_API int vhip_rows_written(const vhip_decoder *p);
+VHIP_API int vhip_code_K(int code);
+VHIP_API int vhip_code_R(int code);
 /* Bytes of HBM the handle holds (decision history + metrics + staging). */
-size_t vhip_device_bytes(const vhip_decoder *p);
+VHIP_API size_t vhip_device_bytes(const vhip_decoder *p);
 
 /* ------------------------------------------------------------------------------------------------
  * Synthetic frames (analogue of src/util.h:8-62: random payload -> convolutional encoder -> soft symbols).
@@ -162,15 +169,15 @@ size_t vhip_device_bytes(const vhip_decoder *p);
  *   symbol = clamp(round(127.5 + amp*(2c-1) + noise), 0, 255), noise = Irwin-Hall(8) scaled by noise_q12
  * amp_q16 = amplitude * 65536 (127.5*65536 with noise_q12 = 0 gives the reference's hard 0/255 symbols).
  * ------------------------------------------------------------------------------------------------ */
-int vhip_noise_q12_from_ebn0(int R, double amp, double ebn0_db);
-int vhip_gen_frames_host(int K, int R, const int *poly, uint64_t seed, uint64_t frame0, int nframes,
+VHIP_API int vhip_noise_q12_from_ebn0(int R, double amp, double ebn0_db);
+VHIP_API int vhip_gen_frames_host(int K, int R, const int *poly, uint64_t seed, uint64_t frame0, int nframes,
                          int payload_bytes, int amp_q16, int noise_q12, unsigned char *payload,
                          unsigned char *syms);
-int vhip_gen_frames_dev(int K, int R, const int *poly, uint64_t seed, uint64_t frame0, int nframes,
+VHIP_API int vhip_gen_frames_dev(int K, int R, const int *poly, uint64_t seed, uint64_t frame0, int nframes,
                         int payload_bytes, int amp_q16, int noise_q12, unsigned char *d_payload,
                         unsigned char *d_syms, void *stream);
 /* Bit errors between two device byte buffers (BER reduction, src/util.h:64-73), blocking. */
-long long vhip_count_bit_errors_dev(const unsigned char *d_a, const unsigned char *d_b, size_t nbytes,
+VHIP_API long long vhip_count_bit_errors_dev(const unsigned char *d_a, const unsigned char *d_b, size_t nbytes,
                                     void *stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -179,11 +186,11 @@ long long vhip_count_bit_errors_dev(const unsigned char *d_a, const unsigned cha
  * ------------------------------------------------------------------------------------------------ */
 #define VHIP_DECLARE_FIVE(T, CREATE, INIT, UPDATE, CHAINBACK, DELETE)                                   \
     struct T;                                                                                           \
-    struct T *CREATE(const int *poly, int len);                                                         \
-    int INIT(struct T *p, int starting_state);                                                          \
-    void UPDATE(struct T *p, unsigned char *syms, int nbits);                                           \
-    int CHAINBACK(struct T *p, unsigned char *data, unsigned int nbits, unsigned int endstate);         \
-    void DELETE(struct T *p);
+    VHIP_API struct T *CREATE(const int *poly, int len);                                                \
+    VHIP_API int INIT(struct T *p, int starting_state);                                                 \
+    VHIP_API void UPDATE(struct T *p, unsigned char *syms, int nbits);                                  \
+    VHIP_API int CHAINBACK(struct T *p, unsigned char *data, unsigned int nbits, unsigned int endstate);\
+    VHIP_API void DELETE(struct T *p);
 
 /* replaces ka9q_libfec_port/viterbi27_sse2.h:3-8 */
 VHIP_DECLARE_FIVE(v27_hip, create_viterbi27_hip, init_viterbi27_hip, update_viterbi27_blk_hip,

@@ -579,36 +579,6 @@ __global__ __launch_bounds__(THREADS, 2) void decode_windowed_k15_kernel(DecodeW
     acs_k15_body<SP, true>(a);
 }
 
-#ifndef VH_JIT_KERNEL
-// chainback over the K=15 layout; same walk as chainback_viterbi615_sse2 (viterbi615_sse2.cpp:65-91, 32-bit word
-// semantics -- SURVEY.md §0.3).  One thread per frame; one dependent 4-byte load per decoded bit.
-__global__ __launch_bounds__(64) void chainback_k15_kernel(ChainbackRowsArgs a) {
-    const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= a.nframes) return;
-    constexpr int sub = NB - 8;
-    unsigned char *out = a.data + f * (long)a.data_stride;
-    const unsigned *rows = reinterpret_cast<const unsigned *>(a.dec) + f * (long)a.cap_rows * 512L;
-    unsigned e = a.endstate % N;
-    int rot = (int)(a.nbits % NB);  // (r+1) mod 14 at the first row visited (r = nbits-1 + 14)
-    for (unsigned i = a.nbits; i-- > 0;) {
-        const long r = (long)i + NB;
-        unsigned k = 0;
-        if (r < a.rows_written) {
-            const unsigned p = rot == 0 ? e : (((e >> rot) | (e << (NB - rot))) & (N - 1u));
-            const int phi = rot == 0 ? NB - 1 : rot - 1;  // phase of row r
-            const unsigned t = phi < 7 ? (p & 127u) : (p >> 7), q = phi < 7 ? (p >> 7) : (p & 127u);
-            const unsigned rho = q >> 1, h = q & 1u;
-            const unsigned word = rows[r * 512L + (rho >> 4) * 128 + t];
-            k = (word >> k15_decision_bit(a.k15_sign_bytes != 0, rho, h)) & 1u;
-        }
-        e = (k << (K - 2)) | (e >> 1);                                   // viterbi615_sse2.cpp:87
-        if ((i & 7u) == 0) out[i >> 3] = (unsigned char)(e >> sub);      // :88
-        rot = rot == 0 ? NB - 1 : rot - 1;
-    }
-}
-
-#endif  // !VH_JIT_KERNEL
-
 }  // namespace k15
 
 #ifndef VH_JIT_KERNEL
@@ -636,11 +606,6 @@ hipError_t launch_decode_windowed_k15(bool spiral, const unsigned char *syms, si
     const int grid = nframes < 1024 ? nframes : 1024;
     if (spiral) hipLaunchKernelGGL(k15::decode_windowed_k15_kernel<true>, dim3(grid), dim3(k15::THREADS), 0, stream, a);
     else hipLaunchKernelGGL(k15::decode_windowed_k15_kernel<false>, dim3(grid), dim3(k15::THREADS), 0, stream, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_chainback_k15(const ChainbackRowsArgs &a, hipStream_t stream) {
-    hipLaunchKernelGGL(k15::chainback_k15_kernel, dim3((a.nframes + 63) / 64), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -38,7 +38,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int K = 24, NB = 23;
+constexpr int NB = 23;
 constexpr unsigned N = 1u << NB;
 constexpr int POLY[2] = {062650457, 062650455};  // src/main.cpp:415
 
@@ -293,33 +293,6 @@ __global__ __launch_bounds__(256) void acs_k24f_pass_kernel(const int16_t *oldm,
     }
 }
 
-// chainback over position-bitmap rows; same walk as chainback_viterbi224_sse2 (viterbi224_sse2.cpp:79-121): no tail
-// skip, emits the bit that falls off the right end of the state, stores a byte only when nbits%8 == 0.
-template <bool TILED>
-__global__ void chainback_k24f_kernel(ChainbackRowsArgs a) {
-    const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= a.nframes) return;
-    unsigned char *out = a.data + f * (long)a.data_stride;
-    const unsigned char *rows = a.dec + f * (long)a.cap_rows * (N / 8);
-    unsigned e = a.endstate & (N - 1u);
-    unsigned dbyte = 0;
-    int rot = (int)(a.nbits % NB);  // (r+1) mod 23 for the first row visited, r = nbits-1
-    for (unsigned i = a.nbits; i-- > 0;) {
-        dbyte = ((e & 1u) << 7) | (dbyte >> 1);
-        if ((i & 7u) == 0) out[i >> 3] = (unsigned char)dbyte;
-        unsigned bit = 0;
-        if ((int)i < a.rows_written) {
-            const unsigned p = rot == 0 ? e : (((e >> rot) | (e << (NB - rot))) & (N - 1u));
-            unsigned widx, wbit;
-            if constexpr (TILED) k24t_locate(p, rot == 0 ? NB - 1 : rot - 1, widx, wbit);
-            else k24f_locate(p, rot == 0 ? NB - 1 : rot - 1, widx, wbit);
-            bit = (reinterpret_cast<const unsigned *>(rows + (size_t)i * (N / 8))[widx] >> wbit) & 1u;
-        }
-        e = (bit << (K - 2)) | (e >> 1);
-        rot = rot == 0 ? NB - 1 : rot - 1;
-    }
-}
-
 }  // namespace k24f
 
 bool k24f_poly_supported(const int *poly) { return poly[0] == k24f::POLY[0] && poly[1] == k24f::POLY[1]; }
@@ -353,12 +326,6 @@ hipError_t launch_k24f_pass(int g, const int16_t *oldm, int16_t *newm, unsigned 
         break;
     default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
-}
-
-hipError_t launch_chainback_k24f(const ChainbackRowsArgs &a, bool tiled, hipStream_t stream) {
-    if (tiled) hipLaunchKernelGGL(k24f::chainback_k24f_kernel<true>, dim3((a.nframes + 63) / 64), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL(k24f::chainback_k24f_kernel<false>, dim3((a.nframes + 63) / 64), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -446,16 +446,20 @@ static hipError_t launch_pass_mode(int pass, const int16_t *oldm, int16_t *newm,
 
 hipError_t launch_k24t_pass(int pass, const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,
                             int rel_row0, int s_lo, int s_hi, int *flags, K24Report mirror, hipStream_t stream, bool nt_stores, int ctl) {
-    static const int mode = getenv("VHIP_K24T_MODE") ? atoi(getenv("VHIP_K24T_MODE")) : 0;  // timing experiments only
+#ifdef VHIP_TIMING_BUILD
+    // tools/k24t_probe.sh only (make -C csrc timing -> libviterbi_hip_timing.so): the MODE instantiations skip stores or
+    // regrouping and give WRONG results by design; none of this is compiled into libviterbi_hip.so
+    static const int mode = getenv("VHIP_K24T_MODE") ? atoi(getenv("VHIP_K24T_MODE")) : 0;
     if (mode == 1) return launch_pass_mode<1>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
     if (mode == 3) return launch_pass_mode<3>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
     if (mode == 2) return launch_pass_mode<2>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
     if (mode == 4) return launch_pass_mode<4>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
     if (mode == 5) return launch_pass_mode<5>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
     static const int nt_env = getenv("VHIP_K24T_NT") ? atoi(getenv("VHIP_K24T_NT")) : -1;  // A/B switch for the non-temporal hints
-    const int nt = nt_env >= 0 ? nt_env : (nt_stores ? 2 : 0);
-    if (nt == 0) return launch_pass_mode<0, 0>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
-    if (nt == 3) return launch_pass_mode<0, 3>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
+    if (nt_env == 3) return launch_pass_mode<0, 3>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
+    if (nt_env >= 0) nt_stores = nt_env != 0;
+#endif
+    if (!nt_stores) return launch_pass_mode<0, 0>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
     return launch_pass_mode<0>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
 }
 
@@ -464,10 +468,13 @@ hipError_t launch_k24t_pass(int pass, const int16_t *oldm, int16_t *newm, unsign
 }  // namespace vh
 
 #ifdef VH_JIT_KERNEL
+#ifndef VH_JIT_NT
+#define VH_JIT_NT 2  // metric stores non-temporal (a lone decode); 0 = plain (several decodes share the chip)
+#endif
 #define VH_JIT_PASS(NAME, BODY, FULL, BOUNDS)                                                                                    \
     extern "C" __global__ BOUNDS void NAME(const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,  \
                                            int rel_row0, int s_lo, int s_hi, int *flags, vh::K24Report mirror, int ctl) {        \
-        vh::k24t::BODY<FULL, 0, 2>(oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, ctl);                            \
+        vh::k24t::BODY<FULL, 0, VH_JIT_NT>(oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, ctl);                            \
     }
 VH_JIT_PASS(vh_jit_k24t_h_full, pass_h_body, true, __launch_bounds__(512))
 VH_JIT_PASS(vh_jit_k24t_h_part, pass_h_body, false, __launch_bounds__(512))

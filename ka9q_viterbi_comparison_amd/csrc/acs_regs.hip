@@ -20,7 +20,7 @@
 //    compile-time constant; the branch metric of a butterfly is a static pick from 2^R per-step values.
 //  * Decisions: min(positive-part, 1<<k) turns a packed ACS by-product into bit k / bit 16+k, OR-ed into
 //    accumulators; one 32-bit word per 16 registers leaves per step, laid out [group][row][word][lane] so a
-//    wave store is 256 contiguous bytes.  chainback_regs_kernel below walks exactly this layout.
+//    wave store is 256 contiguous bytes.  the chainback kernels below walk exactly this layout.
 //
 // Algorithmic HBM bytes per frame-step are those of the reference layout: R symbol bytes in, N/8 decision
 // bytes out; the metrics never leave the register file during a launch.
@@ -832,120 +832,12 @@ hipError_t launch_acs_regs(int code, int lb, const AcsRegsArgs &a, hipStream_t s
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// chainback over the [group][row][word][lane] decision layout: one thread per frame.
+// chainback over the [group][row][word][lane] decision layout: one thread per frame, one wave per 64 frames.
 // Same walk as chainback_viterbi27_sse2 (viterbi27_sse2.cpp:78-105) / chainback_spiral47 (spiral47.cpp:84-121);
-// the decision of new state n at row r sits at position rotr^((r+1) mod NB)(n).
-__global__ __launch_bounds__(64) void chainback_regs_kernel(ChainbackRegsArgs a) {
-    const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= a.nframes) return;
-    const int K = a.K, NB = K - 1, LB = a.lay.lb, L = 1 << LB;
-    const unsigned N = 1u << NB;
-    const long g = f / a.lay.fpw, fl = f % a.lay.fpw;
-    const int add = (NB < 8) ? 8 - NB : 0;
-    const int sub = (NB > 8) ? NB - 8 : 0;
-    unsigned char *out = a.data + f * (long)a.data_stride;
-    unsigned e = (a.endstate % N) << add;
-    const long rowstride = (long)a.lay.dw * 64 * a.lay.wbytes;
-    const unsigned char *base = a.dec + (g * a.cap_rows) * rowstride + (fl * L) * a.lay.wbytes;
-    int rot = (int)((a.nbits - 1 + NB + 1) % NB);  // (r+1) mod NB for the first row visited, r = nbits-1+K-1
-    for (unsigned i = a.nbits; i-- > 0;) {
-        const unsigned st = e >> add;
-        const long r = (long)i + NB;
-        unsigned k = 0;
-        if (r < a.rows_written) {
-            const unsigned p = rot == 0 ? st : (((st >> rot) | (st << (NB - rot))) & (N - 1));
-            const unsigned lam = p & (L - 1), h = (p >> LB) & 1u, rho = p >> (LB + 1);
-            const unsigned w = rho / a.lay.nrw, bit = (rho % a.lay.nrw) + a.lay.nrw * h;
-            const unsigned char *wp = base + r * rowstride + ((long)w * 64 + lam) * a.lay.wbytes;
-            const unsigned word = a.lay.wbytes == 4 ? *reinterpret_cast<const unsigned *>(wp)
-                                                    : *reinterpret_cast<const unsigned short *>(wp);
-            k = (word >> bit) & 1u;
-        }
-        e = (e >> 1) | (k << (K - 2 + add));
-        if ((i & 7u) == 0) out[i >> 3] = (unsigned char)(e >> sub);
-        rot = rot == 0 ? NB - 1 : rot - 1;
-    }
-}
-
-// Pipelined form of the same walk.  In this layout the bytes holding a frame's decisions for row r do not
-// depend on the state (all N/8 bytes of the row belong to the frame's own L lanes), so the loads of D rows are
-// issued together, ahead of the serial state recurrence; the dependent part of a step is then a register select
-// plus shifts.  HBM bytes read = the whole decision history (N/8 per frame-row) instead of one word per step.
-template <int K, int LB, int D>
-__global__ __launch_bounds__(64) void chainback_regs_pipe_kernel(ChainbackRegsArgs a) {
-    constexpr int NB = K - 1, L = 1 << LB;
-    constexpr unsigned N = 1u << NB;
-    constexpr int NR = N / (2 * L), NRW = NR < 16 ? NR : 16, DW = NR / NRW, WB = NRW == 16 ? 4 : 2;
-    constexpr int CHB = L * WB;           // contiguous bytes of this frame per (row, word index)
-    constexpr int CHD = CHB >= 4 ? CHB / 4 : 1;  // dwords loaded per chunk (a 2-byte chunk is loaded as u16)
-    constexpr int QD = DW * CHD;          // dwords per frame-row held in registers
-    constexpr int FPW = 64 / L;
-    constexpr int add = (NB < 8) ? 8 - NB : 0, sub = (NB > 8) ? NB - 8 : 0;
-    const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= a.nframes) return;
-    const long g = f / FPW, fl = f % FPW;
-    unsigned char *out = a.data + f * (long)a.data_stride;
-    constexpr long rowstride = (long)DW * 64 * WB;
-    const unsigned char *base = a.dec + (g * a.cap_rows) * rowstride + (fl * L) * WB;
-    unsigned e = (a.endstate % N) << add;
-    int rot = (int)(a.nbits % NB);  // (r+1) mod NB at the first row visited, r = nbits-1 + NB
-
-    auto step = [&](unsigned i, const unsigned (&q)[QD], bool have) {
-        const unsigned st = e >> add;
-        unsigned k = 0;
-        if (have) {
-            const unsigned p = rot == 0 ? st : (((st >> rot) | (st << (NB - rot))) & (N - 1));
-            const unsigned lam = p & (L - 1), h = (p >> LB) & 1u, rho = p >> (LB + 1);
-            const unsigned w = rho / NRW, bit = (rho % NRW) + NRW * h;
-            const unsigned byteoff = w * CHB + lam * WB;       // inside the frame's QD*4 bytes (chunks packed per w)
-            const unsigned qi = CHB >= 4 ? byteoff / 4 : w;    // 2-byte chunks occupy one register each
-            const unsigned sh = (CHB >= 4 ? (byteoff & 3u) * 8 : 0) + bit;
-            unsigned word = q[0];
-#pragma unroll
-            for (int t = 1; t < QD; t++) word = (qi == (unsigned)t) ? q[t] : word;
-            k = (word >> sh) & 1u;
-        }
-        e = (e >> 1) | (k << (K - 2 + add));
-        if ((i & 7u) == 0) out[i >> 3] = (unsigned char)(e >> sub);
-        rot = rot == 0 ? NB - 1 : rot - 1;
-    };
-    auto load_row = [&](long r, unsigned (&q)[QD]) {
-        const unsigned char *rp = base + r * rowstride;
-#pragma unroll
-        for (int w = 0; w < DW; w++) {
-            const unsigned char *cp = rp + (long)w * 64 * WB;
-            if constexpr (CHB >= 4) {
-#pragma unroll
-                for (int d = 0; d < CHD; d++) q[w * CHD + d] = reinterpret_cast<const unsigned *>(cp)[d];
-            } else {
-                q[w] = *reinterpret_cast<const unsigned short *>(cp);
-            }
-        }
-    };
-
-    unsigned i = a.nbits;
-    // rows at or beyond rows_written read as zero: walk them one at a time (uniform across the launch)
-    while (i > 0 && (long)(i - 1) + NB >= a.rows_written) {
-        --i;
-        unsigned q[QD] = {};
-        step(i, q, false);
-    }
-    while (i >= (unsigned)D) {
-        unsigned q[D][QD];
-#pragma unroll
-        for (int d = 0; d < D; d++) load_row((long)(i - 1 - d) + NB, q[d]);
-#pragma unroll
-        for (int d = 0; d < D; d++) step(i - 1 - d, q[d], true);
-        i -= D;
-    }
-    while (i > 0) {
-        --i;
-        unsigned q[QD];
-        load_row((long)i + NB, q);
-        step(i, q, true);
-    }
-}
-
+// the decision of new state n at row r sits at position rotr^((r+1) mod NB)(n).  In this layout the bytes holding a
+// frame's decisions for row r do not depend on the state (all N/8 bytes of the row belong to the frame's own L lanes),
+// so the history is streamed ahead of the serial state recurrence.
+//
 // LDS-staged form: one wave per 64 frames streams the decision history of its groups through a double-buffered LDS
 // ring with direct global->LDS loads (global_load_lds_dwordx4, 1 KiB per instruction, no VGPR staging), D rows per
 // buffer; the loads of block n+1 are in flight while block n is walked out of LDS.  Same walk, same bytes.
@@ -1222,29 +1114,18 @@ __global__ __launch_bounds__(64) void chainback_k7_lds_kernel(ChainbackRegsArgs 
 
 hipError_t launch_chainback_regs(const ChainbackRegsArgs &a, hipStream_t stream) {
     const int blocks = (a.nframes + 63) / 64;
-    const bool pipe = getenv("VHIP_CHAINBACK_SIMPLE") == nullptr;
-    if (pipe && !getenv("VHIP_CHAINBACK_PIPE")) {  // default: LDS-staged (K=9: 0.93 -> 0.48 ms on 32768 frames)
-        if (a.K == 7 && a.lay.lb == 0 && !getenv("VHIP_CHAINBACK_GENERIC_LDS")) {
-            hipLaunchKernelGGL((chainback_k7_lds_kernel<32, 32>), dim3(blocks), dim3(64), 0, stream, a);
-            return hipGetLastError();
-        }
+    if (a.K == 7 && a.lay.lb == 0) {
+        hipLaunchKernelGGL((chainback_k7_lds_kernel<32, 32>), dim3(blocks), dim3(64), 0, stream, a);
+        return hipGetLastError();
+    }
 #define VH_CBL(KK, LBB, DD)                                                                                      \
     if (a.K == KK && a.lay.lb == LBB) {                                                                          \
         hipLaunchKernelGGL((chainback_regs_lds_kernel<KK, LBB, DD>), dim3(blocks), dim3(64), 0, stream, a);      \
         return hipGetLastError();                                                                                \
     }
-        VH_CBL(7, 0, 32) VH_CBL(7, 1, 32) VH_CBL(7, 2, 32) VH_CBL(9, 0, 12) VH_CBL(9, 1, 12) VH_CBL(9, 2, 12)
+    VH_CBL(7, 1, 32) VH_CBL(7, 2, 32) VH_CBL(9, 0, 12) VH_CBL(9, 1, 12) VH_CBL(9, 2, 12)
 #undef VH_CBL
-    }
-#define VH_CB(KK, LBB, DD)                                                                                       \
-    if (pipe && a.K == KK && a.lay.lb == LBB) {                                                                  \
-        hipLaunchKernelGGL((chainback_regs_pipe_kernel<KK, LBB, DD>), dim3(blocks), dim3(64), 0, stream, a);     \
-        return hipGetLastError();                                                                                \
-    }
-    VH_CB(7, 0, 16) VH_CB(7, 1, 16) VH_CB(7, 2, 16) VH_CB(9, 0, 8) VH_CB(9, 1, 8) VH_CB(9, 2, 8)
-#undef VH_CB
-    hipLaunchKernelGGL(chainback_regs_kernel, dim3(blocks), dim3(64), 0, stream, a);
-    return hipGetLastError();
+    return hipErrorInvalidValue;  // no such decision layout
 }
 
 #endif  // !VH_JIT_KERNEL

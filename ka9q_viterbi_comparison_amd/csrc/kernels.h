@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 namespace vh {
 
@@ -115,7 +116,6 @@ void windowed_k15_params(int *depth, int *block);
 hipError_t launch_decode_windowed_k15(bool spiral, const unsigned char *syms, size_t sym_stride, int nsteps, int nframes, unsigned char *data,
                                       size_t data_stride, unsigned nbits, unsigned *ring, hipStream_t stream);
 hipError_t launch_acs_k15(const AcsK15Args &a, bool spiral, hipStream_t stream);  // spiral: the spiral615 arithmetic
-hipError_t launch_chainback_k15(const ChainbackRowsArgs &a, hipStream_t stream);
 
 // ---------------------------------------------------------------- chainback.hip (natural rows)
 struct ChainbackRowsArgs {
@@ -161,7 +161,6 @@ hipError_t launch_k24_flags_reset(int *flags, hipStream_t stream);
 bool k24f_poly_supported(const int *poly);
 hipError_t launch_k24f_pass(int g, const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,
                             int rel_row0, int s_lo, int s_hi, int *flags, K24Report mirror, hipStream_t stream);
-hipError_t launch_chainback_k24f(const ChainbackRowsArgs &a, bool tiled, hipStream_t stream);  // tiled: k24t_layout.h rows
 
 // ---------------------------------------------------------------- acs_k24t.hip (K = 24, two passes per 23 steps)
 bool k24t_poly_supported(const int *poly);
@@ -171,7 +170,8 @@ hipError_t launch_k24t_pass(int pass, const int16_t *oldm, int16_t *newm, unsign
 
 // ---------------------------------------------------------------- jit.hip (fast kernels for other polynomials)
 bool jit_enabled();  // VHIP_JIT=0 turns the runtime specialisation off
-bool jit_function(const char *src, const std::string &defs, const char *kname, hipFunction_t *fn, std::string *err);
+// defs: one compiler argument each (no shell is involved)
+bool jit_function(const char *src, const std::vector<std::string> &defs, const char *kname, hipFunction_t *fn, std::string *err);
 std::string jit_poly_define(const int *poly, int n);
 
 // ---------------------------------------------------------------- chainback_spec.hip (K = 15 / 24, one wave per frame)

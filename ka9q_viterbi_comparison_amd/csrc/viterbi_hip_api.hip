@@ -275,16 +275,12 @@ int auto_regs_lb(int code, int nframes) {
     while (lb < 2 && (long)nframes * (1 << lb) < 64L * 768) lb++;
     if (vhip_code_K(code) == 9) lb = 2;
     while (!vh::regs_lanes_supported(code, lb) && lb < 2) lb++;
-    if (const char *e = getenv("VHIP_REGS_LB")) {
-        const int v = atoi(e);
-        if (vh::regs_lanes_supported(code, v)) lb = v;
-    }
-    return lb;
+    return lb;  // vhip_set_variant(VHIP_VARIANT_REGS | ((lb + 1) << 8)) forces another value per handle
 }
 
 int auto_variant(const vhip_decoder *p) {
     if (p->code == VHIP_KA9Q224) {
-        if (vh::k24t_poly_supported(p->poly) && !getenv("VHIP_K24_FUSED")) return VHIP_VARIANT_HBM_TILED;
+        if (vh::k24t_poly_supported(p->poly)) return VHIP_VARIANT_HBM_TILED;
         return vh::k24f_poly_supported(p->poly) ? VHIP_VARIANT_HBM_FUSED : VHIP_VARIANT_HBM;
     }
     if (p->K <= 9 && vh::regs_poly_supported(p->code, p->poly)) {
@@ -310,15 +306,22 @@ bool setup_jit(vhip_decoder *p, int lb, std::string *err) {
         *err = "runtime specialisation is switched off (VHIP_JIT=0)";
         return false;
     }
+    if (use_device(p) != 0) {  // the module is loaded on the current device: make that the handle's
+        *err = "cannot select the handle's device";
+        return false;
+    }
     const std::string poly = vh::jit_poly_define(p->poly, p->R);
     if (p->code == VHIP_KA9Q224) {
+        // metric stores: non-temporal for a lone decode, plain when several decodes share the chip -- the choice
+        // launch_k24t_pass makes for the built-in kernels
+        const std::string nt = p->nframes < K24_WORKERS_MIN_PLAIN ? "-DVH_JIT_NT=2" : "-DVH_JIT_NT=0";
         const char *names[4] = {"vh_jit_k24t_h_full", "vh_jit_k24t_h_part", "vh_jit_k24t_l_full", "vh_jit_k24t_l_part"};
         for (int i = 0; i < 4; i++)
-            if (!vh::jit_function("acs_k24t.hip", poly, names[i], &p->jit_fn[i], err)) return false;
+            if (!vh::jit_function("acs_k24t.hip", {poly, nt}, names[i], &p->jit_fn[i], err)) return false;
         return true;
     }
     if (p->K == 15)
-        return vh::jit_function("acs_k15.hip", poly + (p->code == VHIP_SPIRAL615 ? " -DVH_JIT_SPIRAL=true" : " -DVH_JIT_SPIRAL=false"), "vh_jit_acs_k15",
+        return vh::jit_function("acs_k15.hip", {poly, p->code == VHIP_SPIRAL615 ? "-DVH_JIT_SPIRAL=true" : "-DVH_JIT_SPIRAL=false"}, "vh_jit_acs_k15",
                                 &p->jit_fn[0], err);
     const char *traits = p->code == VHIP_KA9Q27 ? "Code27" : p->code == VHIP_KA9Q29 ? "Code29" : p->code == VHIP_SPIRAL47 ? "Code47"
                        : p->code == VHIP_SPIRAL49 ? "Code49" : p->code == VHIP_SPIRAL27 ? "CodeS27" : p->code == VHIP_SPIRAL29 ? "CodeS29" : nullptr;
@@ -327,9 +330,10 @@ bool setup_jit(vhip_decoder *p, int lb, std::string *err) {
         return false;
     }
     const int nr = (int)(p->N >> (lb + 1));  // packed registers per lane: >= 32 takes the two-waves-per-SIMD scheduling hint, as launch_regs
-    std::string defs = std::string("-DVH_JIT_CODE=") + traits + " " + poly + " -DVH_JIT_LB=" + std::to_string(lb);
-    defs += nr >= 32 ? " '-DVH_JIT_ATTR=__attribute__((amdgpu_waves_per_eu(1,2)))'" : " -DVH_JIT_ATTR=";
-    return vh::jit_function("acs_regs.hip", defs, "vh_jit_acs_regs", &p->jit_fn[0], err);
+    return vh::jit_function("acs_regs.hip",
+                            {std::string("-DVH_JIT_CODE=") + traits, poly, "-DVH_JIT_LB=" + std::to_string(lb),
+                             nr >= 32 ? "-DVH_JIT_ATTR=__attribute__((amdgpu_waves_per_eu(1,2)))" : "-DVH_JIT_ATTR="},
+                            "vh_jit_acs_regs", &p->jit_fn[0], err);
 }
 
 void apply_variant(vhip_decoder *p, int variant, int lb) {
@@ -774,6 +778,7 @@ int vhip_set_pipeline_depth(vhip_decoder *p, int depth) {
     HIP_TRY(hipStreamSynchronize(p->stream));
     const size_t dec_bytes = (size_t)p->frames_padded * (size_t)p->cap_rows * p->row_bytes;
     const size_t met_bytes = (size_t)p->nframes * p->N * sizeof(int16_t);
+    const size_t bytes_before = p->total_bytes;
     p->slots[0].d_dec = p->d_dec;
     p->slots[0].d_metrics = p->d_metrics;
     hipError_t e = hipEventCreateWithFlags(&p->ev_input, hipEventDisableTiming);
@@ -791,9 +796,25 @@ int vhip_set_pipeline_depth(vhip_decoder *p, int depth) {
     }
     if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // the hipMemset fills above: the slot streams are non-blocking
+    if (e != hipSuccess) {
+        // a slot without its stream or history must never be rotated into: release what was created and stay serial
+        for (int i = 0; i < depth; i++) {
+            vhip_decoder::Slot &sl = p->slots[i];
+            if (i > 0 && sl.d_dec) (void)hipFree(sl.d_dec);
+            if (i > 0 && sl.d_metrics) (void)hipFree(sl.d_metrics);
+            if (sl.stream) (void)hipStreamDestroy(sl.stream);
+            if (sl.done) (void)hipEventDestroy(sl.done);
+            sl = vhip_decoder::Slot{};
+        }
+        if (p->ev_input) (void)hipEventDestroy(p->ev_input);
+        p->ev_input = nullptr;
+        p->total_bytes = bytes_before;
+        p->depth = 1;
+        p->cur_slot = 0;
+        return fail("set_pipeline_depth: allocation (the handle stays at depth 1)", e);
+    }
     p->depth = depth;  // from here on vhip_delete releases the slots
     p->cur_slot = 0;
-    if (e != hipSuccess) return fail("set_pipeline_depth: allocation", e);
     return 0;
 }
 
@@ -811,6 +832,7 @@ int vhip_join(vhip_decoder *p) {
 
 int vhip_set_variant(vhip_decoder *p, int variant) {
     if (!p) return fail("set_variant: NULL handle");
+    if (use_device(p) != 0) return -1;
     if (p->pos != 0) return fail("set_variant: only before the first update after init");
     // bits 8.. optionally carry 1 + log2(lanes per frame) for the REGS kernels
     const int lb_req = (variant >> 8) - 1;
@@ -987,11 +1009,8 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
         a.endstate = endstate;
         a.K = p->K;
         a.k224 = 1;
-        if (getenv("VHIP_CHAINBACK_SIMPLE")) HIP_TRY(vh::launch_chainback_k24f(a, tiled, p->stream));
-        else {
-            if (setup_segments(p, a) != 0) return -1;
-            HIP_TRY(vh::launch_chainback_spec(tiled ? vh::CB_LAY_K24T : vh::CB_LAY_K24F, a, p->stream));
-        }
+        if (setup_segments(p, a) != 0) return -1;
+        HIP_TRY(vh::launch_chainback_spec(tiled ? vh::CB_LAY_K24T : vh::CB_LAY_K24F, a, p->stream));
         return 0;
     }
     if (p->variant == VHIP_VARIANT_REGS && p->K == 15) {
@@ -1007,11 +1026,8 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
         a.K = p->K;
         a.k224 = 0;
         a.k15_sign_bytes = p->code == VHIP_KA9Q615;
-        if (getenv("VHIP_CHAINBACK_SIMPLE")) HIP_TRY(vh::launch_chainback_k15(a, p->run_stream()));
-        else {
-            if (setup_segments(p, a) != 0) return -1;
-            HIP_TRY(vh::launch_chainback_spec(a.k15_sign_bytes ? vh::CB_LAY_K15_SIGN_BYTES : vh::CB_LAY_K15, a, p->run_stream()));
-        }
+        if (setup_segments(p, a) != 0) return -1;
+        HIP_TRY(vh::launch_chainback_spec(a.k15_sign_bytes ? vh::CB_LAY_K15_SIGN_BYTES : vh::CB_LAY_K15, a, p->run_stream()));
         return 0;
     }
     if (p->variant == VHIP_VARIANT_REGS) {
@@ -1040,7 +1056,7 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
     a.endstate = endstate;
     a.K = p->K;
     a.k224 = (p->code == VHIP_KA9Q224);
-    if (p->K >= 15 && !getenv("VHIP_CHAINBACK_SIMPLE")) {
+    if (p->K >= 15) {
         if (setup_segments(p, a) != 0) return -1;
         HIP_TRY(vh::launch_chainback_spec(vh::CB_LAY_NATURAL, a, p->run_stream()));
     } else HIP_TRY(vh::launch_chainback_rows(a, p->run_stream()));
@@ -1109,10 +1125,14 @@ int vhip_decode_windowed_dev(vhip_decoder *p, const unsigned char *d_syms, unsig
     const int steps_run = p->incremental ? steps : (steps / 2) * 2;  // update_spiral47 drops an odd last step (spiral47.cpp:536-538)
     if (p->K == 15) {
         // the decision ring of the resident workgroups (320 KiB each, at most 1024): allocated on first use, kept with the handle
+        // One ring set per pipeline slot: on a pipelined handle vhip_init() rotates the slot, and the persistent grids of two
+        // consecutive decodes then run at the same time on two internal streams.
         const size_t need = vh::windowed_k15_ring_bytes(p->nframes);
-        if (ensure_stage(&p->d_ring, &p->ring_bytes, need, &p->total_bytes) != 0) return -1;
+        if (p->ring_bytes < need * (size_t)p->depth && sync_all(p) != 0) return -1;  // a smaller ring may still be in use
+        if (ensure_stage(&p->d_ring, &p->ring_bytes, need * (size_t)p->depth, &p->total_bytes) != 0) return -1;
+        unsigned char *ring = p->d_ring + (size_t)(p->depth > 1 ? p->cur_slot : 0) * need;
         HIP_TRY(vh::launch_decode_windowed_k15(p->code == VHIP_SPIRAL615, d_syms, (size_t)steps * p->R, steps_run, p->nframes, d_data, (nbits + 7) / 8,
-                                               nbits, reinterpret_cast<unsigned *>(p->d_ring), p->run_stream()));
+                                               nbits, reinterpret_cast<unsigned *>(ring), p->run_stream()));
         return 0;
     }
     HIP_TRY(vh::launch_decode_windowed(p->code, d_syms, (size_t)steps * p->R, steps_run, p->nframes, d_data, (nbits + 7) / 8, nbits, p->run_stream()));

@@ -34,6 +34,38 @@ def test_library_exports_every_declared_symbol():
     assert set(names) <= bound, f"ctypes binding is missing {set(names) - bound}"
 
 
+def test_library_exports_nothing_else():
+    """-fvisibility=hidden + csrc/exports.map: the dynamic symbol table IS the header -- no vh:: internals, kernel stubs,
+    std:: instantiations or HIP registration symbols a host program could collide with."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == header_functions(), sorted(set(exported) ^ set(header_functions()))
+
+
+def test_shipping_library_has_no_timing_modes():
+    """The K=24 timing experiments (VHIP_K24T_MODE, results wrong by design) live in `make timing` only."""
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"VHIP_K24T_MODE", b"VHIP_K24T_NT", b"VHIP_CHAINBACK_SIMPLE", b"VHIP_CHAINBACK_PIPE", b"VHIP_K24_FUSED", b"VHIP_REGS_LB"):
+        assert name not in blob, name
+
+
+def test_jit_fingerprint_matches_the_sources():
+    """jit.hip refuses run-time builds unless the kernel sources next to the library are the ones it was built from."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_hash import fnv1a64_of_files
+
+    csrc = os.path.dirname(_lib.LIB_PATH)
+    names = ["acs_regs.hip", "acs_k15.hip", "acs_k24t.hip", "kernels.h", "viterbi_codes.h", "k24t_layout.h", "k15_layout.h"]
+    baked = re.search(r"VH_JIT_SOURCES_HASH 0x([0-9a-f]+)ull", open(os.path.join(csrc, "jit_sources_hash.h")).read()).group(1)
+    assert int(baked, 16) == fnv1a64_of_files([os.path.join(csrc, n) for n in names])
+    # the same list, in the same order, on both sides
+    assert all(n in open(os.path.join(csrc, "jit.hip")).read() for n in names)
+
+
 def test_code_table():
     lib = _lib.load()
     for spec in codes.CODES.values():

@@ -148,3 +148,43 @@ def test_fused_decode_handle_holds_no_history():
     assert count_bit_errors_dev(d_out, d_payload, frames_ * B, stream) == 0
     assert dec.device_bytes < 4 << 30
     dec.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["615", "27"])
+def test_fused_decode_on_a_pipelined_handle(name):
+    """vhip_set_pipeline_depth(2) + vhip_init() between two fused decodes: the two kernels run at the same time on the two
+    internal streams.  The K=15 kernel keeps its decision rings in global memory -- one ring set per pipeline slot, or the
+    two grids overwrite each other's rows.  Both outputs must equal those of a serial handle."""
+    import torch
+
+    from ka9q_viterbi_comparison_amd import HipViterbi, gen_frames_dev, noise_q12
+
+    spec = C.CODES[name]
+    bits, nframes = 1024, 300  # 300 workgroups per grid: both grids are resident together
+    B, steps = bits // 8, bits + spec.K - 1
+    stream = torch.cuda.current_stream().cuda_stream
+    syms, outs, refs = [], [], []
+    for s in range(2):
+        d_payload = torch.empty(nframes * B, dtype=torch.uint8, device="cuda")
+        d_syms = torch.empty(nframes * steps * spec.R, dtype=torch.uint8, device="cuda")
+        gen_frames_dev(spec, 50 + s, 0, nframes, B, C.SOFT_AMP_Q16, noise_q12(spec.R, C.SOFT_AMP, spec.ebn0_db - 1.0), d_payload, d_syms, stream)
+        syms.append(d_syms)
+        outs.append(torch.zeros(nframes * B, dtype=torch.uint8, device="cuda"))
+        refs.append(torch.zeros(nframes * B, dtype=torch.uint8, device="cuda"))
+    serial = HipViterbi(name, steps, nframes=nframes, stream=stream)
+    for s in range(2):
+        serial.decode_windowed(syms[s], bits, refs[s])
+        serial.sync()
+    serial.close()
+    piped = HipViterbi(name, steps, nframes=nframes, stream=stream, pipeline_depth=2)
+    for rep in range(3):
+        for s in range(2):
+            piped.reset()  # rotates the slot: the next decode runs on the other internal stream
+            piped.decode_windowed(syms[s], bits, outs[s])
+        piped.join()
+        torch.cuda.synchronize()
+        for s in range(2):
+            assert torch.equal(outs[s], refs[s]), (name, rep, s)
+            outs[s].zero_()
+    piped.close()

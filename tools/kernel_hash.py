@@ -26,3 +26,23 @@ def kernel_source_hash(family):
             h.update(rel.encode())
             h.update(open(path, "rb").read())
     return h.hexdigest()[:16]
+
+
+def fnv1a64_of_files(paths):
+    """FNV-1a/64 over the concatenated contents: the fingerprint csrc/Makefile bakes into libviterbi_hip.so
+    (jit_sources_hash.h) and jit.hip recomputes before every run-time build."""
+    h = 0xCBF29CE484222325
+    for path in paths:
+        for b in open(path, "rb").read():
+            h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+if __name__ == "__main__":
+    import sys
+
+    if len(sys.argv) > 2 and sys.argv[1] == "--fnv":
+        print(f"{fnv1a64_of_files(sys.argv[2:]):016x}")
+    else:
+        for fam in KERNEL_SOURCES:
+            print(fam, kernel_source_hash(fam))
