@@ -97,12 +97,18 @@ def cpu_baseline(spec, payload_bits, budget_s=12.0):
         return n, el.value
 
     try:
-        cores = len(os.sched_getaffinity(0))
+        cores_available = len(os.sched_getaffinity(0))
     except Exception:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))  # the GPU box gives one GPU a 16-core share
+        cores_available = os.cpu_count() or 1
+    cores = max(1, min(cores_available, 16))  # the GPU box gives one GPU a 16-core share
     if spec.K == 24:
         cores = min(cores, 4)      # each K=24 handle holds 32 MiB of metrics + 1 MiB per step
+    flags_file = os.path.join(ROOT, "oracle", "_ref", "build_flags.txt")
+    if use_ref:
+        build = open(flags_file).read().strip() if os.path.exists(flags_file) else "g++ -std=c++17 -O3 -msse4.1 (oracle/Makefile REF_CXXFLAGS)"
+        build += "; the reference's own presets add -march=native -ffast-math (CMakePresets.json:36-56), not used: the objects must run on any host"
+    else:
+        build = "gcc -O2 -std=gnu99 (oracle/Makefile CFLAGS), scalar C"
     decs = [make() for _ in range(cores)]  # created serially: the reference's table init is not thread-safe
     n1, t1 = work(decs[0], budget_s * 0.4)
     single = n1 * steps * spec.R / t1 / 1e6
@@ -118,7 +124,9 @@ def cpu_baseline(spec, payload_bits, budget_s=12.0):
         "value": round(multi, 6),
         "unit": "Msymbols/s",
         "cores": cores,
+        "cores_available": cores_available,
         "kind": "reference" if use_ref else "port",
+        "build": build,
         "single_thread_value": round(single, 6),
         "sample": f"{n1} (1 thread) + {nall} ({cores} threads) one-frame decodes (reset+update+chainback) of K={spec.K} "
                   f"r=1/{spec.R} x {payload_bits} bits, AWGN Eb/N0={spec.ebn0_db} dB, {budget_s:.0f} s budget",
@@ -256,6 +264,109 @@ def replayed_counter(kind, code, family):
     return v, f"replayed from {os.path.relpath(path, ROOT)} (rocprofv3 --pmc, sources {v.get('kernel_source_sha256')}); not measured in this run"
 
 
+# ------------------------------------------------------------------------------------------------ one JSON object per workload
+def report(args, spec, frames, core, shard, with_cpu, cpu_budget):
+    """The bench line of one workload from the job loop's core figures and the shard's kernel timings."""
+    st = core.pop("stats")
+    n_gpus, nsteps, payload_bits = core["n_gpus"], shard.nsteps, shard.payload_bits
+    upd_ms, cb_ms = st["update_ms"], st["chainback_ms"]
+    variant = st["variant"]
+    family = kernel_family(spec.K)
+    abytes = algorithmic_bytes_per_frame_step(spec) * frames * nsteps  # per pass of one rank (SURVEY.md §8d)
+    mbytes = moved_bytes_per_frame_step(spec, variant, {4: 5, 5: 2}.get(variant)) * frames * nsteps
+    achieved = mbytes / (upd_ms * 1e-3) / 1e9
+    tv, tsrc = replayed_counter("traffic", args.code, family)
+    vv, vsrc = replayed_counter("valu", args.code, family)
+    valu = None
+    if vv is not None:
+        # instructions per launch come from the committed PMC pass; the time is this run's
+        rate = vv["valu_wave_instr_per_launch"] / (upd_ms * 1e-3) / 1e9
+        valu = {"wave_instr_per_launch": vv["valu_wave_instr_per_launch"], "achieved_ginstr_per_s": round(rate, 2),
+                "issue_ceiling_ginstr_per_s": round(vv["issue_ceiling_ginstr_per_s"], 2),
+                "frac": round(rate / vv["issue_ceiling_ginstr_per_s"], 4),
+                # the same kernel with nothing else on the device (roofline.alone)
+                "frac_alone": round(vv["valu_wave_instr_per_launch"] / (st["update_ms_alone"] * 1e-3) / 1e9 / vv["issue_ceiling_ginstr_per_s"], 4),
+                "source": vsrc}
+    out = {
+        "metric": f"Msymbols/s decoded, K={spec.K} r=1/{spec.R} " + ("(fused sliding-window decode: NOT the reference chainback semantics)" if shard.windowed else "(init + ACS update + chainback)"),
+        "value": round(core["value"] / 1e6, 6),
+        "unit": "Msymbols/s",
+        "n_gpus": n_gpus,
+        "steps": core["steps"],
+        "warmup": core["warmup"],
+        "ms_per_step": round(core["ms_per_step"], 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8" if spec.family != "ka9q-i16-sat" else "i16",
+        "data": "synthetic" + (" hard 0/255 symbols" if args.hard else f" AWGN Eb/N0={shard.ebn0} dB, amplitude {C.SOFT_AMP}") + ", generated on device",
+        "config": {"workload": f"viterbi{spec.name}: K={spec.K} r=1/{spec.R}, {frames} frames/GPU x {payload_bits} info bits "
+                               f"({nsteps} trellis steps, {nsteps * spec.R} symbols/frame)",
+                   "frames_per_gpu": frames, "chunk_frames": shard.chunk, "payload_bits": payload_bits, "variant": variant,
+                   "pipeline_depth": shard.depth,
+                   "parallelism": f"frame-shard x{n_gpus}, no collective"},
+        "update_msym_s": round(frames * nsteps * spec.R * n_gpus / (upd_ms * 1e-3) / 1e6, 6),
+        "chainback_mbit_s": round(frames * shard.cb_bits * n_gpus / (cb_ms * 1e-3) / 1e6, 3) if cb_ms > 0 else None,
+        "update_ms": round(upd_ms, 4),
+        "chainback_ms": round(cb_ms, 4),
+        "kernel_timing": "HIP events recorded by the library around its launches, on the streams they run on, timed region only"
+                         + ("; update and chainback of consecutive steps overlap (pipeline depth 2), so the two do not add up to ms_per_step" if shard.depth > 1 else ""),
+        "bit_errors": int(core["bit_errors"]),
+        "payload_bits_total": frames * payload_bits * n_gpus,
+        # achieved = bytes the ACS kernels move per pass / their event-timed duration; for K <= 15 that IS the
+        # algorithmic figure of SURVEY.md §8d, for the multi-step K=24 passes it is what the passes really move
+        "roofline": {"bound": "hbm", "kernel": "acs_update", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     "traffic": (tv or {}).get("hbm_bytes_per_launch"), "traffic_source": tsrc,
+                     "bytes_per_launch": int(mbytes), "algorithmic_bytes_per_launch": int(abytes),
+                     # On a double-buffered handle consecutive update kernels overlap each other and the previous
+                     # chainback, so one launch lasts longer than the interval at which launches complete:
+                     # `frac` above divides by the launch duration (the contract), this one by ms_per_step
+                     "per_step": {"achieved": round(mbytes / (core["ms_per_step"] * 1e-3) / 1e9, 2),
+                                  "frac": round(mbytes / (core["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                     # the same kernel with nothing else on the device (3 passes after the timed region)
+                     "alone": {"update_ms": round(st["update_ms_alone"], 4), "achieved": round(mbytes / (st["update_ms_alone"] * 1e-3) / 1e9, 2),
+                               "frac": round(mbytes / (st["update_ms_alone"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                               "chainback_ms": round(st["chainback_ms_alone"], 4)}},
+        # the binding limit of the K<=15 ACS kernels (DESIGN.md §4.1): packed-integer VALU issue, not HBM
+        "valu_issue": valu,
+    }
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline(spec, payload_bits, cpu_budget)
+    return out
+
+
+# BASELINE.json configs[2] and configs[3] ride on the same line as the headline (configs[1]) under "extra.configs", so the
+# driver-run record carries every single-GPU configuration: fewer steps and a shorter CPU sample each, same fields.
+EXTRA_CONFIGS = [("615", 10, 2, 4.0), ("224", 10, 2, 1.0)]  # (code, steps, warmup, cpu budget s; one K=24 CPU decode takes ~5 s whatever the budget)
+
+
+def run_extra_config(base_args, code, steps, warmup, cpu_budget, dev):
+    args = argparse.Namespace(**vars(base_args))
+    args.code, args.frames, args.payload_bits, args.variant, args.chunk_frames, args.windowed = code, None, None, 0, None, False
+    args.ebn0, args.hard = None, False
+    spec = C.CODES[code]
+    frames = DEFAULT_FRAMES[spec.K]
+    holder = {}
+
+    def make_shard(frame_lo, nframes):
+        holder["shard"] = HipShard(args, spec, dev, frame_lo, nframes)
+        return holder["shard"]
+
+    core = run_sharded_job(make_shard, frames_per_rank=frames, steps=steps, warmup=warmup, rank=0, world=1, device=dev, reduce_device=None)
+    shard = holder["shard"]
+    try:
+        return report(args, spec, frames, core, shard, not base_args.no_cpu_baseline, min(cpu_budget, base_args.cpu_budget))
+    finally:
+        shard.close()
+        del holder["shard"], shard
+        torch.cuda.empty_cache()
+
+
+# BASELINE.json configs: K=7 x 65536 frames, K=15 x 4096 frames, K=24 single long frame; K=9 sized in between
+DEFAULT_FRAMES = {7: 65536, 9: 32768, 15: 4096, 24: 1}
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -276,6 +387,8 @@ def main():
     ap.add_argument("--windowed", action="store_true", help="K<=9: time the fused sliding-window decode (one kernel, no decision history in HBM) "
                                                             "instead of init + update + chainback; results are NOT those of the reference chainback")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--no-extra-configs", action="store_true", help="only the headline workload (default: at N=1 with the default workload, BASELINE "
+                                                                    "configs[2] K=15 x 4096 and configs[3] K=24 x 1 follow under extra.configs)")
     args = ap.parse_args()
     if args.no_pipeline:
         args.pipeline_depth = 1
@@ -301,9 +414,7 @@ def main():
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
     spec = C.CODES[args.code]
-    # BASELINE.json configs: K=7 x 65536 frames, K=15 x 4096 frames, K=24 single long frame; K=9 sized in between
-    default_frames = {7: 65536, 9: 32768, 15: 4096, 24: 1}
-    frames = args.frames or default_frames[spec.K]
+    frames = args.frames or DEFAULT_FRAMES[spec.K]
     dev = torch.device("cuda", dev_index)
     rdev = dev if backend == "nccl" else None  # where the scalar reductions live
     holder = {}
@@ -315,76 +426,25 @@ def main():
     core = run_sharded_job(make_shard, frames_per_rank=frames, steps=args.steps, warmup=args.warmup, rank=rank, world=world,
                            device=dev, reduce_device=rdev)
     shard = holder["shard"]
-
+    out = None
     if rank == 0:
-        st = core.pop("stats")
-        n_gpus, nsteps, payload_bits = core["n_gpus"], shard.nsteps, shard.payload_bits
-        upd_ms, cb_ms = st["update_ms"], st["chainback_ms"]
-        variant = st["variant"]
-        family = kernel_family(spec.K)
-        abytes = algorithmic_bytes_per_frame_step(spec) * frames * nsteps  # per pass of one rank
-        mbytes = moved_bytes_per_frame_step(spec, variant, {4: 5, 5: 2}.get(variant)) * frames * nsteps
-        achieved = mbytes / (upd_ms * 1e-3) / 1e9
-        tv, tsrc = replayed_counter("traffic", args.code, family)
-        vv, vsrc = replayed_counter("valu", args.code, family)
-        valu = None
-        if vv is not None:
-            # instructions per launch come from the committed PMC pass; the time is this run's
-            rate = vv["valu_wave_instr_per_launch"] / (upd_ms * 1e-3) / 1e9
-            valu = {"wave_instr_per_launch": vv["valu_wave_instr_per_launch"], "achieved_ginstr_per_s": round(rate, 2),
-                    "issue_ceiling_ginstr_per_s": round(vv["issue_ceiling_ginstr_per_s"], 2),
-                    "frac": round(rate / vv["issue_ceiling_ginstr_per_s"], 4),
-                    # the same kernel with nothing else on the device (roofline.alone)
-                    "frac_alone": round(vv["valu_wave_instr_per_launch"] / (st["update_ms_alone"] * 1e-3) / 1e9 / vv["issue_ceiling_ginstr_per_s"], 4),
-                    "source": vsrc}
-        out = {
-            "metric": f"Msymbols/s decoded, K={spec.K} r=1/{spec.R} " + ("(fused sliding-window decode: NOT the reference chainback semantics)" if shard.windowed else "(init + ACS update + chainback)"),
-            "value": round(core["value"] / 1e6, 6),
-            "unit": "Msymbols/s",
-            "n_gpus": n_gpus,
-            "steps": core["steps"],
-            "warmup": core["warmup"],
-            "ms_per_step": round(core["ms_per_step"], 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8" if spec.family != "ka9q-i16-sat" else "i16",
-            "data": "synthetic" + (" hard 0/255 symbols" if args.hard else f" AWGN Eb/N0={shard.ebn0} dB, amplitude {C.SOFT_AMP}") + ", generated on device",
-            "config": {"workload": f"viterbi{spec.name}: K={spec.K} r=1/{spec.R}, {frames} frames/GPU x {payload_bits} info bits "
-                                   f"({nsteps} trellis steps, {nsteps * spec.R} symbols/frame)",
-                       "frames_per_gpu": frames, "chunk_frames": shard.chunk, "payload_bits": payload_bits, "variant": variant,
-                       "pipeline_depth": shard.depth,
-                       "parallelism": f"frame-shard x{n_gpus}, no collective"},
-            "update_msym_s": round(frames * nsteps * spec.R * n_gpus / (upd_ms * 1e-3) / 1e6, 6),
-            "chainback_mbit_s": round(frames * shard.cb_bits * n_gpus / (cb_ms * 1e-3) / 1e6, 3) if cb_ms > 0 else None,
-            "update_ms": round(upd_ms, 4),
-            "chainback_ms": round(cb_ms, 4),
-            "kernel_timing": "HIP events recorded by the library around its launches, on the streams they run on, timed region only"
-                             + ("; update and chainback of consecutive steps overlap (pipeline depth 2), so the two do not add up to ms_per_step" if shard.depth > 1 else ""),
-            "bit_errors": int(core["bit_errors"]),
-            "payload_bits_total": frames * payload_bits * n_gpus,
-            # achieved = bytes the ACS kernels move per pass / their event-timed duration; for K <= 15 that IS the
-            # algorithmic figure of SURVEY.md §8d, for the multi-step K=24 passes it is what the passes really move
-            "roofline": {"bound": "hbm", "kernel": "acs_update", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": (tv or {}).get("hbm_bytes_per_launch"), "traffic_source": tsrc,
-                         "bytes_per_launch": int(mbytes), "algorithmic_bytes_per_launch": int(abytes),
-                         # On a double-buffered handle consecutive update kernels overlap each other and the previous
-                         # chainback, so one launch lasts longer than the interval at which launches complete:
-                         # `frac` above divides by the launch duration (the contract), this one by ms_per_step
-                         "per_step": {"achieved": round(mbytes / (core["ms_per_step"] * 1e-3) / 1e9, 2),
-                                      "frac": round(mbytes / (core["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-                         # the same kernel with nothing else on the device (3 passes after the timed region)
-                         "alone": {"update_ms": round(st["update_ms_alone"], 4), "achieved": round(mbytes / (st["update_ms_alone"] * 1e-3) / 1e9, 2),
-                                   "frac": round(mbytes / (st["update_ms_alone"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                                   "chainback_ms": round(st["chainback_ms_alone"], 4)}},
-            # the binding limit of the K<=15 ACS kernels: packed-integer VALU issue, not HBM
-            "valu_issue": valu,
-        }
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(spec, payload_bits, args.cpu_budget)
-        print(json.dumps(out), flush=True)
+        out = report(args, spec, frames, core, shard, core["n_gpus"] == 1 and not args.no_cpu_baseline, args.cpu_budget)
     shard.close()
+    del holder["shard"], shard
+    default_workload = args.code == "27" and args.frames is None and args.payload_bits is None and not args.windowed and args.variant == 0
+    if rank == 0 and world == 1 and default_workload and not args.no_extra_configs:
+        torch.cuda.empty_cache()
+        extras = []
+        for code, steps, warmup, cpu_budget in EXTRA_CONFIGS:
+            try:
+                extras.append(run_extra_config(args, code, steps, warmup, cpu_budget, dev))
+            except Exception as e:  # noqa: BLE001 -- the headline stands on its own; a failed extra says so
+                extras.append({"config": {"workload": f"viterbi{code}"}, "error": f"{type(e).__name__}: {e}"})
+        out["extra"] = {"note": "BASELINE.json configs[2] (K=15 x 4096 frames) and configs[3] (K=24, one 2048-bit frame), measured after the "
+                                "headline in the same process: same fields, fewer steps, a shorter CPU sample",
+                        "configs": extras}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libviterbi_hip.so")
+# VITERBI_HIP_LIB: tools/k24t_probe.sh points this at csrc/libviterbi_hip_timing.so (`make timing`); nothing else should.
+LIB_PATH = os.environ.get("VITERBI_HIP_LIB") or os.path.join(_HERE, "csrc", "libviterbi_hip.so")
 
 _lib = None
 

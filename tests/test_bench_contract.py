@@ -36,3 +36,27 @@ def test_bench_json_line_contract():
     # value is consistent with ms_per_step and the workload size
     syms = 4096 * (2048 + 6) * 2
     assert abs(d["value"] - syms / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.02
+
+
+@pytest.mark.gpu
+def test_bench_default_line_carries_every_single_gpu_config():
+    """With no workload flags the one JSON line holds BASELINE.json configs[1] as the headline and configs[2] (K=15 x 4096
+    frames) and configs[3] (K=24, one 2048-bit frame) under extra.configs, each with its own value / kernel rates /
+    roofline / cpu_baseline / bit errors."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--cpu-budget", "1"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert "65536 frames" in d["config"]["workload"] and d["steps"] == 3
+    extras = d["extra"]["configs"]
+    assert [("K=15" in e["config"]["workload"], "K=24" in e["config"]["workload"]) for e in extras] == [(True, False), (False, True)]
+    for e in extras:
+        assert "error" not in e, e
+        for k in ("value", "ms_per_step", "update_msym_s", "chainback_mbit_s", "roofline", "cpu_baseline", "bit_errors", "steps", "warmup"):
+            assert k in e, k
+        assert e["value"] > 0 and e["roofline"]["frac"] > 0 and e["cpu_baseline"]["value"] > 0
+        assert e["roofline"]["bytes_per_launch"] > 0 and e["roofline"]["algorithmic_bytes_per_launch"] > 0
+    assert "4096 frames" in extras[0]["config"]["workload"] and extras[0]["dtype"] == "i16"
+    assert "1 frames" in extras[1]["config"]["workload"] and extras[1]["bit_errors"] == 0  # K=24 at 4 dB: error free

@@ -97,6 +97,40 @@ def test_config4_k24_long_frame(bits):
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
+def test_config4_k24_full_frame_against_the_reference():
+    """configs[3] at full size, held to the REFERENCE itself (oracle/_ref, the reference's own translation unit compiled by
+    oracle/Makefile; the plain-C restatement where that library is absent): one 2048-bit K=24 frame at 4 dB -- 2071 trellis
+    steps, about four renormalisations -- through the production kernel (HBM_TILED, what AUTO selects).  Compared: all 8 388 608
+    final path metrics, every decoded byte of both chainback conventions (nbits as the harness calls it, nbits + K - 1 which
+    decodes correctly: SURVEY.md §0.4), and decision rows sampled across the frame (first / last row, both sides of a
+    23-row period boundary, rows around the renormalisations)."""
+    import oracle_lib as ol
+    from common import frames as gen
+
+    spec = C.CODES["224"]
+    bits = 2048
+    B, steps = bits // 8, bits + spec.K - 1
+    payload, syms = gen(spec.code, 0xC4, 1, B, spec.ebn0_db)
+    ref = ol.RefDecoder(spec.code, spec.poly, steps) if ol.have_ref() else OracleDecoder(spec.code, spec.poly, steps)
+    ref.init(0)
+    ref.update(syms[0], steps)
+    dec = HipViterbi("224", steps, nframes=1)
+    assert dec.variant == VARIANT_HBM_TILED
+    dec.reset()
+    dec.update(syms, nbits=steps)
+    assert np.array_equal(dec.metrics(0), ref.metrics()), "final path metrics"
+    for nb in (bits, steps, bits - 5):
+        got, _ = dec.chainback(nb)
+        want, _ = ref.chainback(nb)
+        assert np.array_equal(got[0], want), f"decoded bytes, nbits={nb}"
+    assert np.array_equal(dec.chainback(steps)[0][0][:B], payload[0])
+    rows = ref.rows(steps)
+    for r in (0, 1, 8, 9, 22, 23, 24, 500, 1034, 1035, 1500, 2047, steps - 2, steps - 1):
+        assert np.array_equal(dec.decision_rows(0, r, 1)[0], rows[r]), f"decision row {r}"
+    dec.close()
+    ref.close()
+
+
 @pytest.mark.parametrize("name,frames", [("47", 65536), ("29", 32768), ("49", 32768)])
 def test_sweep_codes_roundtrip(name, frames):
     bits = 2048

@@ -358,6 +358,45 @@ def test_pipelined_handle_matches_oracle(name, depth, nframes):
     ser.close()
 
 
+@pytest.mark.parametrize("name", ["615", "spiral615"])
+def test_first_chainback_of_a_fresh_pipelined_handle(name):
+    """Regression for the one intermittent wrong decode of round 2 (commit 7a7caf7): the first chainback of a K >= 15 handle
+    with <= 64 frames allocates and clears the scratch words of the segment-parallel walk; the clear was a hipMemset on the
+    null stream while the walk ran on a NON-BLOCKING internal stream of the pipelined handle, so the walk could start on
+    words that were cleared under its feet.  The order that raced, on purpose: fresh handle, set_pipeline_depth, then init /
+    update / chainback through the device-pointer API with no host synchronisation anywhere before the join -- for the first
+    decode AND for the decode that first uses the second slot.  Several fresh handles, each compared with the oracle."""
+    import torch
+
+    spec = C.CODES[name]
+    code = spec.code
+    B, nframes = 64, 5  # 512 bits = 8 segments of 64 bits per frame
+    steps = B * 8 + spec.K - 1
+    steps -= 0 if spec_is_incremental(code) else steps % 2
+    stream = torch.cuda.current_stream().cuda_stream
+    _, syms = frames(code, 4242, nframes, B, spec.ebn0_db)
+    syms = np.ascontiguousarray(syms[:, :steps * spec.R])
+    d_syms = torch.from_numpy(syms).cuda()
+    refs = [oracle_decode(code, syms[f], steps, B * 8)["data"] for f in range(nframes)]
+    torch.cuda.synchronize()
+    for trial in range(6):
+        dec = HipViterbi(name, steps, nframes=nframes, stream=stream, pipeline_depth=2)
+        outs = [torch.zeros(nframes * B, dtype=torch.uint8, device="cuda") for _ in range(3)]
+        for k in range(3):  # slot 1, slot 0, slot 1
+            dec.reset()
+            dec.update(d_syms, nbits=steps)
+            dec.chainback(B * 8, out=outs[k])
+        dec.join()
+        torch.cuda.synchronize()
+        rewalked, nseg = dec.chainback_rewalked()
+        assert nseg == 8
+        for k in range(3):
+            got = outs[k].cpu().numpy().reshape(nframes, B)
+            for f in range(nframes):
+                assert np.array_equal(got[f], refs[f]), (name, trial, k, f)
+        dec.close()
+
+
 def test_pipeline_depth_argument_checks():
     from ka9q_viterbi_comparison_amd._lib import VhipError
 
@@ -529,6 +568,50 @@ def test_arbitrary_polynomials(code):
             HipViterbi(spec.name, steps, nframes=1, poly=poly, variant=fast)
     finally:
         del os.environ["VHIP_JIT"]
+
+
+def test_jit_cache_must_be_private(tmp_path):
+    """Run-time builds are cached on disk and loaded into the process, so the cache must be the caller's alone:
+    a cache directory others can write to switches the run-time build off (the handle then runs the any-polynomial
+    kernel, still bit-exact), and a code object planted as a symbolic link is not loaded but rebuilt in place.  Each case is a
+    child process (the library caches loaded modules per process)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import sys; sys.path.insert(0, %r)\n"
+            "from ka9q_viterbi_comparison_amd import HipViterbi\n"
+            "d = HipViterbi('27', 100, nframes=3, poly=(0x5B, 0x79))\n"
+            "print('SPECIALISED' if d.runtime_specialised else 'GENERIC', d.variant & 0xff)\n"
+            "d.close()\n") % root
+
+    def run(cache):
+        env = dict(os.environ, VHIP_JIT_CACHE=str(cache))
+        r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout.split()
+
+    open_dir = tmp_path / "shared"
+    open_dir.mkdir()
+    os.chmod(open_dir, 0o777)
+    assert run(open_dir) == ["GENERIC", str(VARIANT_LDS)]
+    assert not list(open_dir.iterdir()), "nothing may be written to (or loaded from) a cache others can write to"
+    link_target = tmp_path / "elsewhere"
+    link_target.mkdir()
+    link = tmp_path / "cache_link"
+    link.symlink_to(link_target, target_is_directory=True)
+    assert run(link)[0] == "GENERIC"  # the cache path itself must not be a link
+    priv = tmp_path / "private"
+    assert run(priv) == ["SPECIALISED", str(VARIANT_REGS)]
+    assert (os.stat(priv).st_mode & 0o777) == 0o700
+    objs = [p for p in priv.iterdir() if p.suffix == ".hsaco"]
+    assert len(objs) == 1
+    planted = tmp_path / "planted.hsaco"
+    objs[0].rename(planted)
+    objs[0].symlink_to(planted)
+    assert run(priv) == ["SPECIALISED", str(VARIANT_REGS)]
+    assert not objs[0].is_symlink() and objs[0].is_file(), "the link was replaced by a fresh build, not followed"
 
 
 @pytest.mark.parametrize("name,nframes,B", [("27", 16384, 64), ("49", 4096, 64), ("615", 512, 32)])

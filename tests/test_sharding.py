@@ -180,3 +180,52 @@ def test_bench_job_loop_two_ranks(tmp_path):
     payload, _ = frames(C.KA9Q27, 0x5EED, 10, 8, None)
     assert np.array_equal(np.load(tmp_path / "job_out0.npy"), payload[:5])
     assert np.array_equal(np.load(tmp_path / "job_out1.npy"), payload[5:])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """bench.py as the driver launches it for N = 2 (python -m torch.distributed.run --nproc-per-node 2 ... --gpus 2), on the
+    one GPU of the test box: VITERBI_BENCH_BACKEND=gloo lets both ranks share device 0 (RCCL refuses two ranks on one
+    device), everything else is the N-GPU code path.  The launcher is a fresh child process (nothing in it has touched the
+    GPU before torch.distributed.run starts the ranks).  Checked: one JSON line from rank 0 with n_gpus == 2 and twice the
+    single-rank work, and the frame ranges of the two ranks are distinct -- the job's bit-error count equals the sum of the
+    counts of frame ranges [0, F) and [F, 2F) decoded here one after the other, which differ from each other.  No data-path
+    collective exists to check for: the only torch.distributed calls are barrier / MAX / SUM in sharding.py.
+    An 8-GPU RCCL run is NOT covered by this (no such node was available to the builder)."""
+    import argparse
+    import json
+    import subprocess
+
+    import torch
+
+    import bench
+    from ka9q_viterbi_comparison_amd import codes as C
+
+    F, bits, ebn0 = 4096, 512, 2.0
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--code", "27", "--frames", str(F), "--payload-bits", str(bits), "--ebn0", str(ebn0), "--no-cpu-baseline", "--no-extra-configs"]
+    env = dict(os.environ, VITERBI_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["frames_per_gpu"] == F
+    assert "no collective" in d["config"]["parallelism"]
+    assert d["payload_bits_total"] == 2 * F * bits
+    # the same two frame ranges, decoded here by the same shard object
+    spec = C.CODES["27"]
+    args = argparse.Namespace(code="27", payload_bits=bits, ebn0=ebn0, hard=False, variant=0, chunk_frames=None, hbm_budget_gb=200.0,
+                              pipeline_depth=2)
+    errs = []
+    for rank in range(2):
+        shard = bench.HipShard(args, spec, torch.device("cuda", 0), rank * F, F)
+        shard.drain()
+        shard.one_pass(0)
+        shard.one_pass(1)
+        shard.drain()
+        errs.append(shard.stats()["bit_errors"])
+        shard.close()
+    assert errs[0] != errs[1] and min(errs) > 0, errs
+    assert d["bit_errors"] == errs[0] + errs[1], (d["bit_errors"], errs)
