@@ -141,7 +141,9 @@ enum vhip_variant {
     VHIP_VARIANT_REGS = 2,  /* metrics packed in VGPRs: frames across lanes (K<=9), workgroup per frame (K=15) */
     VHIP_VARIANT_HBM = 3,   /* K=24: metrics tiled through HBM, one launch per trellis step */
     VHIP_VARIANT_HBM_FUSED = 4, /* K=24: 4 or 7 trellis steps per pass over the metric array (harness polynomials) */
-    VHIP_VARIANT_HBM_TILED = 5  /* K=24: 9 or 14 steps per pass -- two passes per 23 steps, tiles regrouped through LDS */
+    VHIP_VARIANT_HBM_TILED = 5, /* K=24: 9 or 14 steps per pass -- two passes per 23 steps, tiles regrouped through LDS */
+    VHIP_VARIANT_WAVE = 6   /* K=7: one wavefront per frame, one state per lane -- the latency geometry for handles with few
+                               frames (the reference's one-frame-per-handle methodology, src/main.cpp:257-280); any polynomials */
 };
 VHIP_API int vhip_set_variant(vhip_decoder *p, int variant);
 /* Polynomials other than the reference harness's (src/main.cpp:367-415): the fast kernels are compiled for them when the

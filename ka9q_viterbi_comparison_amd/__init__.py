@@ -14,6 +14,7 @@ from .decoder import (  # noqa: F401
     VARIANT_HBM,
     VARIANT_HBM_FUSED,
     VARIANT_HBM_TILED,
+    VARIANT_WAVE,
     gen_frames_host,
     gen_frames_dev,
     count_bit_errors_dev,

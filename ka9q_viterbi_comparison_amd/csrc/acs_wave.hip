@@ -1,0 +1,361 @@
+// acs_wave.hip -- the LATENCY geometry for K=7: one wavefront = one frame, one trellis state per lane.
+//
+// The reference's own methodology decodes ONE frame per handle, one blocking call at a time (src/main.cpp:257-280), and
+// update_viterbi27_blk_sse2 / update_spiral47 (ka9q_libfec_port/viterbi27_sse2.cpp:119-175, spiral/spiral47.cpp:131-538) walk its
+// trellis steps one after the other.  A frame is a single chain of dependent steps, so what bounds it on a GPU is the number of
+// instructions ONE wave has to issue per step (a lone wave issues one instruction per ~4-5 cycles whatever its kind): the
+// throughput kernels of acs_regs.hip spend ~70 instructions per step on a frame held by four lanes (0.18 us per step).  Here
+// the 64 lanes of a wave hold the 64 path metrics and a step is ~12 instructions:
+//   * the rotating in-place trellis of acs_regs.hip: position p (= lane p) holds state rotl^phi(p) before the step of phase
+//     phi = row mod 6, the butterfly partner is lane p ^ (1 << (5 - phi)) -- one DPP operand (quad_perm), two bank-masked DPP
+//     row shifts, or one v_permlane16/32_swap (gfx950) -- and no metric ever moves;
+//   * the branch metrics do not depend on the path metrics, so the OTHER three waves of the workgroup compute them ahead, for
+//     every class of the branch table, into an LDS table (double-buffered chunks): on the serial chain a step's {t, t'} is one
+//     ds_read_b64 at a per-lane class offset;
+//   * metrics sit in the top byte of a dword: a 32-bit add wraps like _mm_add_epi8 (ka9q) or, as (m << 24) | 0xffffff with the
+//     clamp bit, saturates like _mm_adds_epu8 (spiral), and the sign of a 32-bit difference is that of the 8-bit one;
+//   * the 64 decisions of a step are one ballot; 48 of them are parked in two VGPRs (v_writelane) and leave as one store.
+// Decisions: [frame][row] 64-bit words in POSITION order (bit p of row r = decision of the new state rotl^((r+1) mod 6)(p)):
+// exactly N/8 bytes per frame-row like every other layout.  Any polynomial set works (classes are computed per lane at run
+// time).  Arithmetic per family exactly as acs_lds.hip.  chainback: chainback_wave_kernel below.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "kernels.h"
+#include "viterbi_codes.h"
+
+namespace vh {
+namespace wave7 {
+
+constexpr int K = 7, NB = 6;
+constexpr unsigned N = 64, H = 32;
+constexpr int BLK = 48;        // steps per unrolled block = 8 periods; their rows leave as one 384-byte store
+constexpr int THREADS = 256;   // wave 0 walks the trellis, waves 1..3 fill the branch-metric table of the next chunk
+constexpr int TBL_BYTES = 30720;  // per buffer: CH steps x 2^R classes x 8 bytes, CH a multiple of BLK
+
+template <class F, int... Is>
+__device__ __forceinline__ void sfor_impl(F &&f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int NN, class F>
+__device__ __forceinline__ void sfor(F &&f) {
+    sfor_impl(f, std::make_integer_sequence<int, NN>{});
+}
+
+__host__ __device__ constexpr unsigned rotl6(unsigned x, int s) {
+    s %= NB;
+    return s == 0 ? x : (((x << s) | (x >> (NB - s))) & (N - 1u));
+}
+
+// value of lane (l ^ (1 << B))
+template <int B>
+__device__ __forceinline__ unsigned partner(unsigned x, unsigned lane) {
+    if constexpr (B == 0) {
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+    } else if constexpr (B == 1) {
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+    } else if constexpr (B == 2) {
+        // banks (4 lanes) 0 and 2 of every row of 16 read four lanes up, banks 1 and 3 four lanes down
+        int t = __builtin_amdgcn_update_dpp((int)x, (int)x, 0x104, 0xf, 0x5, false);    // row_shl:4
+        return (unsigned)__builtin_amdgcn_update_dpp(t, (int)x, 0x114, 0xf, 0xa, false);  // row_shr:4
+    } else if constexpr (B == 3) {
+        int t = __builtin_amdgcn_update_dpp((int)x, (int)x, 0x108, 0xf, 0x3, false);    // row_shl:8
+        return (unsigned)__builtin_amdgcn_update_dpp(t, (int)x, 0x118, 0xf, 0xc, false);  // row_shr:8
+    } else if constexpr (B == 4) {
+        // v_permlane16_swap: rows 1,3 of the first operand <-> rows 0,2 of the second.  Both = x: the first comes back as
+        // [x0 x0 x2 x2], the second as [x1 x1 x3 x3] (xr = row r of x): odd rows take the first, even rows the second
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        return (lane & 16u) ? r[0] : r[1];
+    } else {
+        // v_permlane32_swap: upper half of the first operand <-> lower half of the second
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        return (lane & 32u) ? r[0] : r[1];
+    }
+}
+
+// lane LANE of acc <- a wave-uniform value (clang has no builtin for v_writelane_b32)
+template <int LANE>
+__device__ __forceinline__ unsigned writelane(unsigned acc, unsigned sval) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(acc) : "s"(sval), "n"(LANE));
+    return acc;
+}
+
+template <class C>
+__device__ __forceinline__ unsigned to_lane_metric(int m) {
+    if constexpr (C::metric == U8MOD) return ((unsigned)m & 255u) << 24;
+    else return (((unsigned)m & 255u) << 24) | 0x00ffffffu;
+}
+
+// One trellis step at phase PHI.  tv / tcv: the butterfly's branch metrics t and t' in the top byte.  up: this lane holds
+// old[j + H] (position bit 5 - PHI set).  Returns the decision of the new state that now lives in this lane.
+template <class C, int PHI>
+__device__ __forceinline__ bool step(unsigned &M, unsigned tv, unsigned tcv, bool up, unsigned lane) {
+    constexpr int B = NB - 1 - PHI;
+    const unsigned X = partner<B>(M, lane);
+    if constexpr (C::metric == U8MOD) {
+        // lower position: m0 = old[j] + t (self), m1 = old[j+H] + t' (partner); upper position: m2 = old[j] + t' (partner),
+        // m3 = old[j+H] + t (self)                                                       viterbi27_sse2.cpp:149-152
+        const unsigned cs = M + tv, co = X + tcv;
+        const unsigned lo = up ? co : cs, hi = up ? cs : co;
+        const bool d = (int)(lo - hi) > 0;  // cmpgt_epi8(sub_epi8(m0, m1), 0): tie -> lower      :155-156
+        M = d ? hi : lo;                    //                                                    :157-158
+        return d;
+    } else {
+        const unsigned cs = __builtin_elementwise_add_sat(M, tv), co = __builtin_elementwise_add_sat(X, tcv);  // adds_epu8  spiral47.cpp:220-223
+        const unsigned lo = up ? co : cs, hi = up ? cs : co;
+        const bool d = hi <= lo;            // min_epu8 + cmpeq(min, upper): tie -> upper          :224-227
+        M = min(cs, co);
+        return d;
+    }
+}
+
+// spiral47.cpp:313-331: after every step, if new[0] > threshold, subtract the minimum over all states (saturating; nothing
+// is below the minimum).  State 0 is position 0 in every phase: lane 0.
+template <class C>
+__device__ __forceinline__ void renormalise(unsigned &M) {
+    if constexpr (C::renorm) {
+        const unsigned m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)M);
+        if ((m0 >> 24) > (unsigned)C::renorm_thr) M -= wave_min(M) & 0xff000000u;
+    }
+}
+
+struct Args {
+    const unsigned char *syms;
+    size_t sym_stride;
+    int nsteps, row0, cap_rows, nframes;
+    unsigned long long *dec;  // [nframes][cap_rows] position-ordered rows
+    int16_t *metrics;         // [nframes][64] canonical path metrics (natural units)
+    int poly[8];
+};
+
+template <class C>
+__global__ __launch_bounds__(THREADS) void acs_wave_kernel(Args a) {
+    constexpr int R = C::R, NC = 1 << R;
+    constexpr int STEP_BYTES = NC * 8;
+    constexpr int CH = (TBL_BYTES / STEP_BYTES / BLK) * BLK;  // table steps per chunk (960 for r=1/2, 240 for r=1/4)
+    static_assert(CH >= BLK && CH * STEP_BYTES <= TBL_BYTES, "chunk geometry");
+    __shared__ __attribute__((aligned(16))) unsigned char tbl[2][TBL_BYTES];
+
+    const int f = blockIdx.x;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned char *syms = a.syms + (size_t)f * a.sym_stride;
+    unsigned long long *rows = a.dec + (size_t)f * a.cap_rows + a.row0;
+    const int phi0 = a.row0 % NB;
+    const int pre = min(a.nsteps, (NB - phi0) % NB);               // steps up to the first phase-0 row: slow path
+    const int nmain = ((a.nsteps - pre) / BLK) * BLK;              // whole blocks through the table
+    const int nchunks = (nmain + CH - 1) / CH;
+
+    // table of chunk c: for each of its steps and every branch-table class {t << 24, t' << 24}
+    auto fill = [&](int buf, int c) {
+        const int s0 = pre + c * CH, cnt = min(CH, nmain - c * CH);
+        for (int i = (int)tid - 64; i < cnt; i += THREADS - 64) {
+            int s[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) s[r] = syms[(size_t)(s0 + i) * R + r];
+            uint2 *e = reinterpret_cast<uint2 *>(&tbl[buf][i * STEP_BYTES]);
+#pragma unroll
+            for (int cl = 0; cl < NC; cl++) {
+                const int t = C::bm(s, (unsigned)cl);
+                e[cl] = make_uint2((unsigned)t << 24, (unsigned)C::bm_tc(t) << 24);
+            }
+        }
+    };
+
+    // ---- wave 0: the serial chain
+    unsigned M = 0;
+    unsigned cls[NB];     // class of this lane's butterfly at each phase
+    bool up[NB];          // this lane is the upper predecessor at each phase
+    unsigned aoff[NB];    // byte offset of the class entry inside a step's record
+    if (wave == 0) {
+#pragma unroll
+        for (int p = 0; p < NB; p++) {
+            const unsigned st = rotl6(lane, p);                       // old state held at phase p
+            cls[p] = bt_class<R>(st & (H - 1u), a.poly);
+            up[p] = (st >> (NB - 1)) & 1u;
+            aoff[p] = cls[p] * 8u;
+        }
+        M = to_lane_metric<C>(a.metrics[(size_t)f * N + rotl6(lane, phi0)]);
+    }
+    // one step outside the table (the few steps in front of the first phase-0 row and behind the last whole block)
+    auto slow_step = [&](int i) {
+        int s[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) s[r] = syms[(size_t)i * R + r];
+        const int phi = (a.row0 + i) % NB;
+        bool d = false;
+        sfor<NB>([&](auto P) {
+            constexpr int PHI = decltype(P)::value;
+            if (phi == PHI) {  // uniform
+                const int t = C::bm(s, cls[PHI]);
+                d = step<C, PHI>(M, (unsigned)t << 24, (unsigned)C::bm_tc(t) << 24, up[PHI], lane);
+            }
+        });
+        renormalise<C>(M);
+        const unsigned long long row = __builtin_amdgcn_ballot_w64(d);
+        if (lane == 0) rows[i] = row;
+    };
+
+    if (wave == 0) {
+        for (int i = 0; i < pre; i++) slow_step(i);
+    } else if (nchunks > 0) {
+        fill(0, 0);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; c++) {
+        if (wave == 0) {
+            const int cnt = min(CH, nmain - c * CH);
+            const unsigned char *tb = tbl[c & 1];
+            for (int b0 = 0; b0 < cnt; b0 += BLK) {
+                unsigned acc_lo = 0, acc_hi = 0;
+                const unsigned char *blk = tb + b0 * STEP_BYTES;
+                sfor<BLK>([&](auto J) {
+                    constexpr int j = decltype(J)::value, PHI = j % NB;
+                    const uint2 e = *reinterpret_cast<const uint2 *>(blk + aoff[PHI] + j * STEP_BYTES);
+                    const bool d = step<C, PHI>(M, e.x, e.y, up[PHI], lane);
+                    renormalise<C>(M);
+                    const unsigned long long row = __builtin_amdgcn_ballot_w64(d);
+                    acc_lo = writelane<j>(acc_lo, (unsigned)row);
+                    acc_hi = writelane<j>(acc_hi, (unsigned)(row >> 32));
+                });
+                if (lane < (unsigned)BLK) rows[pre + c * CH + b0 + (int)lane] = ((unsigned long long)acc_hi << 32) | acc_lo;
+            }
+        } else if (c + 1 < nchunks) {
+            fill((c + 1) & 1, c + 1);
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        for (int i = pre + nmain; i < a.nsteps; i++) slow_step(i);
+        // position p now holds state rotl^((row0 + nsteps) mod 6)(p)
+        a.metrics[(size_t)f * N + rotl6(lane, (a.row0 + a.nsteps) % NB)] = (int16_t)(M >> 24);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- chainback
+// chainback_viterbi27_sse2 (viterbi27_sse2.cpp:78-105) / chainback_spiral47 (spiral47.cpp:84-121) over position-ordered rows:
+// one wave per frame.  The rows of a frame are contiguous, so lane l fetches row (base + l) of a 64-row chunk with one load,
+// the next chunk is in flight while this one is walked, and a row reaches the walk through v_readlane.  The walk runs in
+// position space (chainback_k7_lds_kernel in acs_regs.hip explains it): p = rotr^rot(state), one traceback step replaces bit
+// (6 - rot) mod 6 of p by the decision -- three dependent instructions per decoded bit, every lane the same walk.  32 decoded
+// bits are one dword of the output.  Ragged ends, rows beyond rows_written (they read as zero) and unaligned outputs take
+// the reference's bit-at-a-time form.
+struct CbArgs {
+    const unsigned long long *dec;
+    int cap_rows, rows_written, nframes;
+    unsigned char *data;
+    size_t data_stride;
+    unsigned nbits, endstate;
+};
+
+__global__ __launch_bounds__(64) void chainback_wave_kernel(CbArgs a) {
+    constexpr int add = 2;  // ADDSHIFT = 8 - (K-1)                                    spiral47.cpp:92-101
+    const int f = blockIdx.x;
+    const unsigned lane = threadIdx.x;
+    const unsigned long long *rows = a.dec + (size_t)f * a.cap_rows;
+    unsigned char *out = a.data + (size_t)f * a.data_stride;
+    unsigned e = (a.endstate % N) << add;
+    int rot = (int)(a.nbits % NB);  // (r + 1) mod 6 at the first row visited, r = nbits - 1 + 6
+
+    auto slow = [&](unsigned i) {  // decoded bit i from row i + 6
+        const long r = (long)i + NB;
+        const unsigned st = e >> add;
+        const unsigned p = rot == 0 ? st : (((st >> rot) | (st << (NB - rot))) & (N - 1u));
+        unsigned k = 0;
+        if (r < a.rows_written) k = (unsigned)(rows[r] >> p) & 1u;
+        e = (e >> 1) | (k << (K - 2 + add));
+        if ((i & 7u) == 0 && lane == 0) out[i >> 3] = (unsigned char)e;
+        rot = rot == 0 ? NB - 1 : rot - 1;
+    };
+
+    unsigned i = a.nbits;
+    while (i > 0 && (long)(i - 1) + NB >= a.rows_written) slow(--i);
+    const bool out_aligned = ((reinterpret_cast<uintptr_t>(a.data) | a.data_stride) & 3) == 0;
+    if (out_aligned) {
+        while (i > 0 && (i & 63u)) slow(--i);  // chunks of 64 rows end on a dword of the output
+        if (i >= 64u) {
+            auto pos = [&]() {
+                const unsigned st = e >> add;
+                return rot == 0 ? st : (((st >> rot) | (st << (NB - rot))) & (N - 1u));
+            };
+            unsigned q = pos();
+            unsigned h = e << 24;  // the last 32 decisions, newest on top: its top byte is the reference's register
+            unsigned long long cur = rows[(long)(i - 64u) + NB + lane];  // lane l: row of decoded bit i - 64 + l
+            while (i >= 64u) {
+                const unsigned long long mine = cur;
+                if (i >= 128u) cur = rows[(long)(i - 128u) + NB + lane];
+                const unsigned mlo = (unsigned)mine, mhi = (unsigned)(mine >> 32);
+                // 64 bits, newest first: bit i - 1 - d is in lane 63 - d; rot at that row = (rot0 - d) mod 6
+                auto walk = [&](auto R0) {
+                    constexpr int ROT0 = decltype(R0)::value;
+                    sfor<64>([&](auto D) {
+                        constexpr int d = decltype(D)::value;
+                        constexpr int rotd = ((ROT0 - d) % NB + NB) % NB, jb = (NB - rotd) % NB;
+                        const unsigned wlo = (unsigned)__builtin_amdgcn_readlane((int)mlo, 63 - d);
+                        const unsigned whi = (unsigned)__builtin_amdgcn_readlane((int)mhi, 63 - d);
+                        const unsigned t = (unsigned)((((unsigned long long)whi << 32) | wlo) >> q);
+                        q = (q & ~(1u << jb)) | ((t << jb) & (1u << jb));
+                        h = (h >> 1) | (t << 31);
+                        if constexpr (d == 31 || d == 63) {
+                            // h = decisions of bits i-32 .. i-1 (d == 31) or i-64 .. i-33: four output bytes, first byte on top
+                            if (lane == 0) *reinterpret_cast<unsigned *>(out + ((i - 1u - d) >> 3)) = __builtin_bswap32(h);
+                        }
+                    });
+                };
+                switch (rot) {  // uniform
+                case 0: walk(std::integral_constant<int, 0>{}); break;
+                case 1: walk(std::integral_constant<int, 1>{}); break;
+                case 2: walk(std::integral_constant<int, 2>{}); break;
+                case 3: walk(std::integral_constant<int, 3>{}); break;
+                case 4: walk(std::integral_constant<int, 4>{}); break;
+                default: walk(std::integral_constant<int, 5>{}); break;
+                }
+                rot = (rot + NB * 11 - 64) % NB;
+                i -= 64u;
+            }
+            e = h >> 24;
+        }
+    }
+    while (i > 0) slow(--i);
+}
+
+}  // namespace wave7
+
+bool wave_code_supported(int code) { return code == VHIP_KA9Q27 || code == VHIP_SPIRAL47 || code == VHIP_SPIRAL27; }
+
+hipError_t launch_acs_wave(int code, const AcsLdsArgs &l, hipStream_t stream) {
+    wave7::Args a;
+    a.syms = l.syms;
+    a.sym_stride = l.sym_stride;
+    a.nsteps = l.nsteps;
+    a.row0 = l.row0;
+    a.cap_rows = l.cap_rows;
+    a.nframes = l.nframes;
+    a.dec = reinterpret_cast<unsigned long long *>(l.dec);
+    a.metrics = l.metrics;
+    for (int r = 0; r < 8; r++) a.poly[r] = l.poly[r];
+    switch (code) {
+    case VHIP_KA9Q27: hipLaunchKernelGGL(wave7::acs_wave_kernel<Code27>, dim3(a.nframes), dim3(wave7::THREADS), 0, stream, a); break;
+    case VHIP_SPIRAL47: hipLaunchKernelGGL(wave7::acs_wave_kernel<Code47>, dim3(a.nframes), dim3(wave7::THREADS), 0, stream, a); break;
+    case VHIP_SPIRAL27: hipLaunchKernelGGL(wave7::acs_wave_kernel<CodeS27>, dim3(a.nframes), dim3(wave7::THREADS), 0, stream, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_chainback_wave(const ChainbackRowsArgs &c, hipStream_t stream) {
+    wave7::CbArgs a;
+    a.dec = reinterpret_cast<const unsigned long long *>(c.dec);
+    a.cap_rows = c.cap_rows;
+    a.rows_written = c.rows_written;
+    a.nframes = c.nframes;
+    a.data = c.data;
+    a.data_stride = c.data_stride;
+    a.nbits = c.nbits;
+    a.endstate = c.endstate;
+    hipLaunchKernelGGL(wave7::chainback_wave_kernel, dim3(a.nframes), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace vh

@@ -121,32 +121,47 @@ bool mkdir_p(const std::string &path) {
     return true;
 }
 
-// A directory only this user can write to, or "" with the reason in *err.
+// A directory only this user can write to, or "" with the reason in *err.  Candidates in order: $VHIP_JIT_CACHE (if set, the
+// only one), $XDG_CACHE_HOME/viterbi_hip_jit, ~/.cache/viterbi_hip_jit, /tmp/viterbi_hip_jit_<uid>.  The checks are the same
+// for all of them, which is what makes the /tmp candidate safe: a directory somebody else created there first is not the
+// caller's and is refused.
+bool private_dir(const std::string &dir, std::string *why) {
+    if (!mkdir_p(dir)) {
+        *why = "cannot create " + dir + ": " + strerror(errno);
+        return false;
+    }
+    struct stat st;
+    if (lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & 077) != 0) {
+        *why = dir + " must be a directory (not a link) owned by the caller with mode 0700";
+        return false;
+    }
+    if (access(dir.c_str(), W_OK | X_OK) != 0) {
+        *why = dir + " is not writable";
+        return false;
+    }
+    return true;
+}
+
 std::string cache_dir(std::string *err) {
-    std::string dir;
-    if (const char *e = getenv("VHIP_JIT_CACHE")) dir = e;
-    else if (const char *x = getenv("XDG_CACHE_HOME"); x && x[0] == '/') dir = std::string(x) + "/viterbi_hip_jit";
+    std::vector<std::string> cand;
+    if (const char *e = getenv("VHIP_JIT_CACHE")) cand.push_back(e);
     else {
+        if (const char *x = getenv("XDG_CACHE_HOME"); x && x[0] == '/') cand.push_back(std::string(x) + "/viterbi_hip_jit");
         const char *home = getenv("HOME");
         if (!home || home[0] != '/') {
             if (const struct passwd *pw = getpwuid(geteuid())) home = pw->pw_dir;
         }
-        if (!home || home[0] != '/') {
-            *err = "no cache directory for run-time builds (set VHIP_JIT_CACHE, XDG_CACHE_HOME or HOME)";
-            return "";
-        }
-        dir = std::string(home) + "/.cache/viterbi_hip_jit";
+        if (home && home[0] == '/' && home[1]) cand.push_back(std::string(home) + "/.cache/viterbi_hip_jit");
+        cand.push_back("/tmp/viterbi_hip_jit_" + std::to_string((long)geteuid()));
     }
-    if (!mkdir_p(dir)) {
-        *err = "cannot create the run-time build cache " + dir + ": " + strerror(errno);
-        return "";
+    std::string reasons;
+    for (const std::string &dir : cand) {
+        std::string why;
+        if (private_dir(dir, &why)) return dir;
+        reasons += (reasons.empty() ? "" : "; ") + why;
     }
-    struct stat st;
-    if (lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & 077) != 0) {
-        *err = "the run-time build cache " + dir + " must be a directory (not a link) owned by the caller with mode 0700; run-time builds are off";
-        return "";
-    }
-    return dir;
+    *err = "no private cache directory for run-time builds (" + reasons + "): run-time builds are off";
+    return "";
 }
 
 // the code object as bytes: only a regular file of the caller's, never through a symbolic link

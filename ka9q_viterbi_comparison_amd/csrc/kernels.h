@@ -65,6 +65,12 @@ hipError_t launch_acs_lds(int code, const AcsLdsArgs &a, hipStream_t stream);
 hipError_t launch_init_metrics(int16_t *metrics, size_t n_per_frame, int nframes, int init_all, int init_start,
                                unsigned start_state, hipStream_t stream);
 
+// ---------------------------------------------------------------- acs_wave.hip (K = 7, one wave per frame: the latency geometry)
+struct ChainbackRowsArgs;
+bool wave_code_supported(int code);
+hipError_t launch_acs_wave(int code, const AcsLdsArgs &a, hipStream_t stream);  // a.dec: [nframes][cap_rows] 64-bit position-ordered rows
+hipError_t launch_chainback_wave(const ChainbackRowsArgs &a, hipStream_t stream);
+
 // ---------------------------------------------------------------- acs_regs.hip (K <= 9, harness polynomials)
 struct RegsLayout {  // decision layout [group][row][word][lane] produced by acs_regs_kernel
     int lb;      // log2(lanes per frame)

@@ -121,6 +121,8 @@ namespace {
 // of 16 MiB of dirty lines: 3.95 -> 3.39 ms per 2071-step frame) and cost 7 % when three decodes share the chip (12 frames on
 // one handle: 1.92 -> 2.07 ms per frame), where the write-back is hidden behind the other decodes' passes.
 constexpr int K24_WORKERS_MIN_PLAIN = 3;
+// K=7 handles with at most this many frames take the one-wave-per-frame kernel (tools/small_batch_probe.py)
+constexpr int WAVE_MAX_FRAMES = 64;
 
 // vhip_status(): -1 after a failed init / update / chainback on the handle, 0 after a successful one.  The reference ABI
 // returns void from update and a path metric (any int) from chainback_viterbi615, so the return value alone cannot
@@ -283,6 +285,10 @@ int auto_variant(const vhip_decoder *p) {
         if (vh::k24t_poly_supported(p->poly)) return VHIP_VARIANT_HBM_TILED;
         return vh::k24f_poly_supported(p->poly) ? VHIP_VARIANT_HBM_FUSED : VHIP_VARIANT_HBM;
     }
+    // K=7 with few frames: one wave per frame, one state per lane -- a frame is a chain of dependent steps and this geometry
+    // issues the fewest instructions per step (acs_wave.hip; 8198-step frame: 0.2 ms against 1.5 ms for the register kernel,
+    // which catches up once its 16-64 frames per wave are all in use)
+    if (p->K == 7 && vh::wave_code_supported(p->code) && p->nframes <= WAVE_MAX_FRAMES) return VHIP_VARIANT_WAVE;
     if (p->K <= 9 && vh::regs_poly_supported(p->code, p->poly)) {
         // K=9 r=1/2 with few frames: one workgroup per frame (256 lanes = 256 states) finishes a 2054-step frame in
         // 0.33 ms, the register kernel (4 lanes per frame, one wave for 16 frames) in 1.09 ms, and the two meet near
@@ -637,7 +643,7 @@ vhip_decoder *vhip_create(int code, const int *poly, int len, int nframes) {
     p->frames_padded = (code == VHIP_KA9Q224) ? nframes : ((nframes + 63) / 64) * 64;
     apply_variant(p, auto_variant(p), auto_regs_lb(code, nframes));
     (void)hipGetDevice(&p->device);
-    if (!fast_poly_supported(p)) {
+    if (p->variant != VHIP_VARIANT_WAVE && !fast_poly_supported(p)) {
         // other polynomials than the harness set: the same fast kernel, compiled for them now (jit.hip); if that is not
         // possible here (no sources / no hipcc / VHIP_JIT=0) the handle keeps the any-polynomial kernel chosen above
         const int lb = auto_regs_lb(code, nframes);
@@ -645,8 +651,10 @@ vhip_decoder *vhip_create(int code, const int *poly, int len, int nframes) {
         if (setup_jit(p, lb, &why)) {
             p->jit = true;
             apply_variant(p, code == VHIP_KA9Q224 ? VHIP_VARIANT_HBM_TILED : VHIP_VARIANT_REGS, lb);
-        } else if (getenv("VHIP_VERBOSE")) {
-            fprintf(stderr, "viterbi_hip: %s -- using the any-polynomial kernels\n", why.c_str());
+        } else {
+            // not an error: the handle works, on the any-polynomial kernels.  vhip_last_error() says why until the next failure.
+            g_last_error = "viterbi_hip: no run-time build of the fast kernel for these polynomials: " + why;
+            if (getenv("VHIP_VERBOSE")) fprintf(stderr, "%s -- using the any-polynomial kernels\n", g_last_error.c_str());
         }
     }
     const size_t dec_bytes = (size_t)p->frames_padded * (size_t)p->cap_rows * p->row_bytes;
@@ -838,6 +846,12 @@ int vhip_set_variant(vhip_decoder *p, int variant) {
     const int lb_req = (variant >> 8) - 1;
     variant &= 0xff;
     if (variant == VHIP_VARIANT_AUTO) variant = auto_variant(p);
+    if (variant == VHIP_VARIANT_WAVE) {
+        if (!vh::wave_code_supported(p->code)) return fail("set_variant: the one-wave-per-frame kernel exists for the K=7 codes only");
+        p->jit = false;
+        apply_variant(p, variant, 0);
+        return 0;
+    }
     const bool wants_fast = (p->code == VHIP_KA9Q224) ? variant == VHIP_VARIANT_HBM_TILED : variant == VHIP_VARIANT_REGS;
     if (wants_fast && !fast_poly_supported(p) && (p->code == VHIP_KA9Q224 || p->K == 15 || p->K <= 9)) {
         const int lb = lb_req >= 0 ? lb_req : auto_regs_lb(p->code, p->nframes);
@@ -934,6 +948,18 @@ int vhip_update_dev(vhip_decoder *p, const unsigned char *d_syms, int nbits) {
                 if (rc != 0) return -1;
             }
         }
+    } else if (p->variant == VHIP_VARIANT_WAVE) {
+        vh::AcsLdsArgs a;
+        a.syms = d_syms;
+        a.sym_stride = sym_stride;
+        a.nsteps = steps;
+        a.row0 = row0;
+        a.cap_rows = p->cap_rows;
+        a.nframes = p->nframes;
+        a.dec = p->d_dec;
+        a.metrics = p->d_metrics;
+        for (int r = 0; r < 8; r++) a.poly[r] = p->poly[r];
+        HIP_TRY(vh::launch_acs_wave(p->code, a, p->run_stream()));
     } else if (p->variant == VHIP_VARIANT_REGS && p->K == 15) {
         vh::AcsK15Args a;
         a.syms = d_syms;
@@ -1011,6 +1037,21 @@ int vhip_chainback_dev(vhip_decoder *p, unsigned char *d_data, unsigned int nbit
         a.k224 = 1;
         if (setup_segments(p, a) != 0) return -1;
         HIP_TRY(vh::launch_chainback_spec(tiled ? vh::CB_LAY_K24T : vh::CB_LAY_K24F, a, p->stream));
+        return 0;
+    }
+    if (p->variant == VHIP_VARIANT_WAVE) {
+        vh::ChainbackRowsArgs a;
+        a.dec = p->d_dec;
+        a.cap_rows = p->cap_rows;
+        a.rows_written = p->pos;
+        a.nframes = p->nframes;
+        a.data = d_data;
+        a.data_stride = (nbits + 7) / 8;
+        a.nbits = nbits;
+        a.endstate = endstate;
+        a.K = p->K;
+        a.k224 = 0;
+        HIP_TRY(vh::launch_chainback_wave(a, p->run_stream()));
         return 0;
     }
     if (p->variant == VHIP_VARIANT_REGS && p->K == 15) {
@@ -1200,6 +1241,21 @@ int vhip_read_decision_rows(vhip_decoder *p, int frame, int row0, int nrows, uns
                 if (tiled) vh::k24t_locate(pos, phi, widx, wbit);
                 else vh::k24f_locate(pos, phi, widx, wbit);
                 if ((rw[widx] >> wbit) & 1u) o[n >> 3] |= (unsigned char)(1u << (n & 7));
+            }
+        }
+        return 0;
+    }
+    if (p->variant == VHIP_VARIANT_WAVE) {
+        // position-ordered 64-bit rows of acs_wave.hip -> natural bitmap: new state n of row r sits at position rotr^((r+1) mod 6)(n)
+        const int NB = p->K - 1;
+        std::vector<unsigned long long> raw((size_t)nrows);
+        HIP_TRY(hipMemcpy(raw.data(), p->d_dec + ((size_t)frame * p->cap_rows + row0) * p->row_bytes, raw.size() * 8, hipMemcpyDeviceToHost));
+        memset(out, 0, (size_t)nrows * p->row_bytes);
+        for (int i = 0; i < nrows; i++) {
+            const int rot = (row0 + i + 1) % NB;
+            for (unsigned n = 0; n < p->N; n++) {
+                const unsigned pos = rot == 0 ? n : (((n >> rot) | (n << (NB - rot))) & (p->N - 1));
+                if ((raw[(size_t)i] >> pos) & 1ull) out[(size_t)i * p->row_bytes + (n >> 3)] |= (unsigned char)(1u << (n & 7));
             }
         }
         return 0;

@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib
 from .codes import BY_ID, CODES
 
-VARIANT_AUTO, VARIANT_LDS, VARIANT_REGS, VARIANT_HBM, VARIANT_HBM_FUSED, VARIANT_HBM_TILED = 0, 1, 2, 3, 4, 5
+VARIANT_AUTO, VARIANT_LDS, VARIANT_REGS, VARIANT_HBM, VARIANT_HBM_FUSED, VARIANT_HBM_TILED, VARIANT_WAVE = 0, 1, 2, 3, 4, 5, 6
 
 
 def _is_torch(x):

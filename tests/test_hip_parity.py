@@ -7,7 +7,7 @@ import pytest
 
 from common import GPU_CODES, bit_errors, frames, spec_of
 from ka9q_viterbi_comparison_amd import HipViterbi, codes as C
-from ka9q_viterbi_comparison_amd import VARIANT_AUTO, VARIANT_HBM, VARIANT_HBM_FUSED, VARIANT_HBM_TILED, VARIANT_LDS, VARIANT_REGS
+from ka9q_viterbi_comparison_amd import VARIANT_AUTO, VARIANT_HBM, VARIANT_HBM_FUSED, VARIANT_HBM_TILED, VARIANT_LDS, VARIANT_REGS, VARIANT_WAVE
 from oracle_lib import OracleDecoder
 
 pytestmark = pytest.mark.gpu
@@ -26,7 +26,7 @@ def variants_for(code):
     if code == C.SPIRAL615:
         return [VARIANT_LDS, VARIANT_REGS]
     if code in (C.KA9Q27, C.SPIRAL47, C.SPIRAL27):
-        return [VARIANT_LDS, regs(0), regs(1), regs(2)]
+        return [VARIANT_LDS, regs(0), regs(1), regs(2), VARIANT_WAVE]
     return [VARIANT_LDS, regs(0), regs(1), regs(2)]
 
 
@@ -545,10 +545,16 @@ def test_arbitrary_polynomials(code):
             o.update(syms[f], steps)
             refs.append((o.rows(steps), o.metrics(), o.chainback(B * 8)[0]))
             o.close()
-        for route in ("default", "generic"):
-            dec = HipViterbi(spec.name, steps, nframes=nframes, poly=poly, variant=VARIANT_AUTO if route == "default" else generic)
-            if route == "default":
-                assert dec.runtime_specialised and (dec.variant & 0xff) == fast, "the run-time build of the fast kernel was not used"
+        for route in ("default", "fast", "generic"):
+            want = {"default": VARIANT_AUTO, "fast": fast, "generic": generic}[route]
+            dec = HipViterbi(spec.name, steps, nframes=nframes, poly=poly, variant=want)
+            if route == "default" and spec.K == 7:
+                # few K=7 frames: the one-wave-per-frame kernel, which takes any polynomials as it is
+                assert not dec.runtime_specialised and dec.variant == VARIANT_WAVE
+            elif route != "generic":
+                from ka9q_viterbi_comparison_amd import _lib as L
+
+                assert dec.runtime_specialised and (dec.variant & 0xff) == fast, "the run-time build of the fast kernel was not used: " + L.last_error()
             else:
                 assert not dec.runtime_specialised and dec.variant == generic
             dec.reset()
@@ -562,7 +568,7 @@ def test_arbitrary_polynomials(code):
     os.environ["VHIP_JIT"] = "0"
     try:
         dec = HipViterbi(spec.name, steps, nframes=1, poly=poly)
-        assert not dec.runtime_specialised and dec.variant == generic
+        assert not dec.runtime_specialised and dec.variant == (VARIANT_WAVE if spec.K == 7 else generic)
         dec.close()
         with pytest.raises(VhipError):
             HipViterbi(spec.name, steps, nframes=1, poly=poly, variant=fast)
@@ -582,7 +588,7 @@ def test_jit_cache_must_be_private(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prog = ("import sys; sys.path.insert(0, %r)\n"
             "from ka9q_viterbi_comparison_amd import HipViterbi\n"
-            "d = HipViterbi('27', 100, nframes=3, poly=(0x5B, 0x79))\n"
+            "d = HipViterbi('49', 100, nframes=3, poly=(0x1EF, 0x19B, 0x127, 0x1F5))\n"
             "print('SPECIALISED' if d.runtime_specialised else 'GENERIC', d.variant & 0xff)\n"
             "d.close()\n") % root
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Update + chainback time of small batches, LDS kernel (one workgroup per frame) vs register kernels (frames across lanes):
-where should the automatic variant switch?  python tools/small_batch_probe.py"""
+"""Update + chainback time of small batches: LDS kernel (one workgroup per frame), register kernels (frames across lanes) and,
+for K=7, the one-wave-per-frame kernel (acs_wave.hip): where should the automatic variant switch?
+python tools/small_batch_probe.py"""
 import os
 import sys
 
@@ -14,13 +15,13 @@ for name in ("27", "47", "29", "49"):
     spec = C.CODES[name]
     B = 256
     steps = B * 8 + spec.K - 1
-    for nframes in (1, 16, 64, 256, 1024, 2048, 4096, 8192, 16384):
+    for nframes in (1, 16, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384):
         d_payload = torch.empty(nframes * B, dtype=torch.uint8, device="cuda")
         d_syms = torch.empty(nframes * steps * spec.R, dtype=torch.uint8, device="cuda")
         d_out = torch.zeros(nframes * B, dtype=torch.uint8, device="cuda")
         gen_frames_dev(spec, 1, 0, nframes, B, C.HARD_AMP_Q16, 0, d_payload, d_syms, stream)
         row = []
-        for variant in (1, 2):
+        for variant in (1, 2) + ((6,) if spec.K == 7 else ()):
             dec = HipViterbi(name, steps, nframes=nframes, variant=variant, stream=stream)
             dec.enable_timing(True)
             for _ in range(3):
@@ -31,4 +32,7 @@ for name in ("27", "47", "29", "49"):
             su, nu, sc, nc = dec.read_timing()
             row.append((su / nu, sc / nc))
             dec.close()
-        print(f"{name} frames {nframes:6d}: LDS update {row[0][0]:8.3f} ms chainback {row[0][1]:7.3f} ms | REGS update {row[1][0]:8.3f} ms chainback {row[1][1]:7.3f} ms", flush=True)
+        line = f"{name} frames {nframes:6d}: LDS update {row[0][0]:8.3f} ms chainback {row[0][1]:7.3f} ms | REGS update {row[1][0]:8.3f} ms chainback {row[1][1]:7.3f} ms"
+        if len(row) > 2:
+            line += f" | WAVE update {row[2][0]:8.3f} ms chainback {row[2][1]:7.3f} ms"
+        print(line, flush=True)
