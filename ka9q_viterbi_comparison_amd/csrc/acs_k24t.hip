@@ -19,6 +19,7 @@
 // up to that row, renormalises and continues.  Passes ping-pong between two buffers so that replay is possible.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -261,6 +262,20 @@ __device__ __forceinline__ void ctl_finish(const i16x2 (&M)[32], int *flags, int
     }
 }
 
+// Timing build only (tools/k24t_probe.sh): delay the workgroups selected by `pattern` before they issue their metric loads, so
+// that one co-resident workgroup's loads and stores fall into the other's arithmetic.  ctl bits 8..15: s_sleep units of 64
+// cycles; bits 16..17: which half waits (1: blockIdx >= grid/2, 2: odd (blockIdx >> 3), 3: odd blockIdx).
+__device__ __forceinline__ void timing_stagger(int ctl) {
+#ifdef VHIP_TIMING_BUILD
+    const int units = (ctl >> 8) & 255, pattern = (ctl >> 16) & 3;
+    const bool late = pattern == 1 ? blockIdx.x >= gridDim.x / 2 : pattern == 2 ? ((blockIdx.x >> 3) & 1u) : pattern == 3 ? (blockIdx.x & 1u) : false;
+    if (late)
+        for (int i = 0; i < units; i++) __builtin_amdgcn_s_sleep(1);
+#else
+    (void)ctl;
+#endif
+}
+
 template <bool FULL, int MODE, int NT = 2>
 __device__ __forceinline__ void pass_h_body(const int16_t *oldm, int16_t *__restrict__ newm, unsigned char *__restrict__ rows,
                                             const unsigned char *syms, int rel_row0, int s_lo, int s_hi, int *flags,
@@ -273,6 +288,7 @@ __device__ __forceinline__ void pass_h_body(const int16_t *oldm, int16_t *__rest
     const unsigned tile = blockIdx.x, tid = threadIdx.x;
     unsigned sy[9];
     load_symbols<9, FULL>(syms, s_lo, s_hi, sy);
+    timing_stagger(ctl);
     i16x2 M[32];
     {
         const unsigned pt = k24t_thread_base(K24T_H1, tile, tid);
@@ -348,6 +364,7 @@ __device__ __forceinline__ void pass_l_body(const int16_t *oldm, int16_t *__rest
     const unsigned tile = blockIdx.x, tid = threadIdx.x;
     unsigned sy[14];
     load_symbols<14, FULL>(syms, s_lo, s_hi, sy);
+    timing_stagger(ctl);
     i16x2 M[32];
     {
         const unsigned pt = k24t_thread_base(K24T_L1, tile, tid);
@@ -431,11 +448,11 @@ template <int MODE, int NT = 2>
 static hipError_t launch_pass_mode(int pass, const int16_t *oldm, int16_t *newm, unsigned char *rows, const unsigned char *syms,
                                    int rel_row0, int s_lo, int s_hi, int *flags, K24Report mirror, hipStream_t stream, int ctl) {
     if (pass == 0) {
-        const bool full = s_lo == 0 && s_hi == 9 && ctl == 0;
+        const bool full = s_lo == 0 && s_hi == 9 && (ctl & 255) == 0;
         if (full) hipLaunchKernelGGL((k24t::acs_k24t_pass_h_kernel<true, MODE, NT>), dim3(256), dim3(512), 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, ctl);
         else hipLaunchKernelGGL((k24t::acs_k24t_pass_h_kernel<false, MODE, NT>), dim3(256), dim3(512), 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, ctl);
     } else if (pass == 1) {
-        const bool full = s_lo == 0 && s_hi == 14 && ctl == 0;
+        const bool full = s_lo == 0 && s_hi == 14 && (ctl & 255) == 0;
         if (full) hipLaunchKernelGGL((k24t::acs_k24t_pass_l_kernel<true, MODE, NT>), dim3(512), dim3(256), 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, ctl);
         else hipLaunchKernelGGL((k24t::acs_k24t_pass_l_kernel<false, MODE, NT>), dim3(512), dim3(256), 0, stream, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, ctl);
     } else {
@@ -455,6 +472,12 @@ hipError_t launch_k24t_pass(int pass, const int16_t *oldm, int16_t *newm, unsign
     if (mode == 2) return launch_pass_mode<2>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
     if (mode == 4) return launch_pass_mode<4>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
     if (mode == 5) return launch_pass_mode<5>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
+    // VHIP_K24T_STAGGER="<pass mask>:<pattern>:<sleep units>": see timing_stagger()
+    static const char *stg = getenv("VHIP_K24T_STAGGER");
+    if (stg) {
+        int pm = 0, pat = 0, units = 0;
+        if (sscanf(stg, "%d:%d:%d", &pm, &pat, &units) == 3 && ((pm >> pass) & 1)) ctl |= ((units & 255) << 8) | ((pat & 3) << 16);
+    }
     static const int nt_env = getenv("VHIP_K24T_NT") ? atoi(getenv("VHIP_K24T_NT")) : -1;  // A/B switch for the non-temporal hints
     if (nt_env == 3) return launch_pass_mode<0, 3>(pass, oldm, newm, rows, syms, rel_row0, s_lo, s_hi, flags, mirror, stream, ctl);
     if (nt_env >= 0) nt_stores = nt_env != 0;

@@ -75,11 +75,14 @@ __device__ __forceinline__ unsigned partner(unsigned x, unsigned lane) {
     }
 }
 
-// lane LANE of acc <- a wave-uniform value (clang has no builtin for v_writelane_b32)
+// lane LANE of acc <- a wave-uniform value.  clang has no builtin for v_writelane_b32, so the LLVM intrinsic is declared
+// directly -- NOT inline assembly: an SGPR written by a VALU instruction (the ballot's v_cmp) needs wait states before
+// v_writelane may read it, and the compiler's hazard recogniser does not look into inline assembly (a first version did
+// that and parked stale ballots).
+extern "C" __device__ int vh_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 template <int LANE>
 __device__ __forceinline__ unsigned writelane(unsigned acc, unsigned sval) {
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(acc) : "s"(sval), "n"(LANE));
-    return acc;
+    return (unsigned)vh_writelane_i32((int)sval, LANE, (int)acc);
 }
 
 template <class C>
@@ -99,8 +102,10 @@ __device__ __forceinline__ bool step(unsigned &M, unsigned tv, unsigned tcv, boo
         // m3 = old[j+H] + t (self)                                                       viterbi27_sse2.cpp:149-152
         const unsigned cs = M + tv, co = X + tcv;
         const unsigned lo = up ? co : cs, hi = up ? cs : co;
-        const bool d = (int)(lo - hi) > 0;  // cmpgt_epi8(sub_epi8(m0, m1), 0): tie -> lower      :155-156
-        M = d ? hi : lo;                    //                                                    :157-158
+        const int diff = (int)(lo - hi);
+        const bool d = diff > 0;            // cmpgt_epi8(sub_epi8(m0, m1), 0): tie -> lower      :155-156
+        // d ? hi : lo without waiting for the compare's lane mask: lo - max(diff, 0) (diff = INT_MIN: d = 0, lo stays)  :157-158
+        M = lo - (unsigned)max(diff, 0);
         return d;
     } else {
         const unsigned cs = __builtin_elementwise_add_sat(M, tv), co = __builtin_elementwise_add_sat(X, tcv);  // adds_epu8  spiral47.cpp:220-223
@@ -113,11 +118,24 @@ __device__ __forceinline__ bool step(unsigned &M, unsigned tv, unsigned tcv, boo
 
 // spiral47.cpp:313-331: after every step, if new[0] > threshold, subtract the minimum over all states (saturating; nothing
 // is below the minimum).  State 0 is position 0 in every phase: lane 0.
+// It fires on most steps of a noisy frame, so the reduction is kept short: four v_min_u32 with a DPP operand leave each row of
+// 16 lanes with its minimum, the four rows meet in scalar registers (v_readlane + s_min), and the subtrahend is an SGPR.
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#define VH_MIN_DPP(ctrl) v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xf, 0xf, true))
+    VH_MIN_DPP(0xB1);   // quad_perm [1,0,3,2]
+    VH_MIN_DPP(0x4E);   // quad_perm [2,3,0,1]
+    VH_MIN_DPP(0x141);  // row_half_mirror
+    VH_MIN_DPP(0x140);  // row_mirror
+#undef VH_MIN_DPP
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(a, b), min(c, d));
+}
 template <class C>
 __device__ __forceinline__ void renormalise(unsigned &M) {
     if constexpr (C::renorm) {
         const unsigned m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)M);
-        if ((m0 >> 24) > (unsigned)C::renorm_thr) M -= wave_min(M) & 0xff000000u;
+        if (m0 > (((unsigned)C::renorm_thr << 24) | 0x00ffffffu)) M -= wave_min_u32(M) & 0xff000000u;
     }
 }
 
