@@ -152,6 +152,10 @@ VHIP_API int vhip_set_variant(vhip_decoder *p, int variant);
  * the sources or hipcc next to the library, or with VHIP_JIT=0, the handle uses the slower any-polynomial kernels
  * (VHIP_VARIANT_LDS / VHIP_VARIANT_HBM) and asking for the fast variant explicitly is an error. */
 VHIP_API int vhip_is_runtime_specialised(const vhip_decoder *p);
+/* Needs no device: 1 if the kernel sources next to the library are the ones it was built from (a fingerprint of their contents
+ * is baked in at build time), 0 if they differ -- run-time builds are then refused, because a kernel with another decision
+ * layout than the library's chainback kernels expect would decode silently wrong --, -1 if they cannot be read. */
+VHIP_API int vhip_runtime_build_sources_ok(void);
 VHIP_API int vhip_get_variant(const vhip_decoder *p);
 
 /* Introspection for parity tests (blocking): natural decision bitmap rows (bit n of a row = new state n,

@@ -66,6 +66,7 @@ SYMBOLS = [
     ("vhip_set_variant", C.c_int, [C.c_void_p, C.c_int]),
     ("vhip_get_variant", C.c_int, [C.c_void_p]),
     ("vhip_is_runtime_specialised", C.c_int, [C.c_void_p]),
+    ("vhip_runtime_build_sources_ok", C.c_int, []),
     ("vhip_read_decision_rows", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("vhip_read_metrics", C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     ("vhip_rows_written", C.c_int, [C.c_void_p]),

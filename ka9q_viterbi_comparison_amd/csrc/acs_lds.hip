@@ -110,8 +110,7 @@ __global__ __launch_bounds__(THREADS) void acs_lds_kernel(AcsLdsArgs a) {
                     int mn = mine[0];
 #pragma unroll
                     for (int i = 1; i < S; i++) mn = min(mn, mine[i]);
-#pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) mn = min(mn, __shfl_xor(mn, off));
+                    mn = wave_min(mn);  // six DPP steps (kernels.h); __shfl_xor would be six ds_bpermute round trips
                     if constexpr (THREADS > 64) {
                         if ((tid & 63) == 0) red[tid >> 6] = mn;
                         __syncthreads();

@@ -253,12 +253,19 @@ __global__ __launch_bounds__(THREADS) void acs_wave_kernel(Args a) {
 
 // ---------------------------------------------------------------------------------------------------- chainback
 // chainback_viterbi27_sse2 (viterbi27_sse2.cpp:78-105) / chainback_spiral47 (spiral47.cpp:84-121) over position-ordered rows:
-// one wave per frame.  The rows of a frame are contiguous, so lane l fetches row (base + l) of a 64-row chunk with one load,
-// the next chunk is in flight while this one is walked, and a row reaches the walk through v_readlane.  The walk runs in
-// position space (chainback_k7_lds_kernel in acs_regs.hip explains it): p = rotr^rot(state), one traceback step replaces bit
-// (6 - rot) mod 6 of p by the decision -- three dependent instructions per decoded bit, every lane the same walk.  32 decoded
-// bits are one dword of the output.  Ragged ends, rows beyond rows_written (they read as zero) and unaligned outputs take
-// the reference's bit-at-a-time form.
+// one wave per frame.  The walk runs in position space (chainback_k7_lds_kernel in acs_regs.hip explains it): p =
+// rotr^rot(state), and one traceback step replaces bit (6 - rot) mod 6 of p by the decision.
+//
+// One frame's walk is a chain of dependent steps, so the 64 lanes SHARE it: the frame is cut into at most 64 segments of S
+// bits (a multiple of 96 = lcm(32 output bits, 6 phases), so every lane is at the same phase in the same loop step and a
+// segment is whole dwords of the output).  Lane 0 walks the top segment from the caller's end state -- exact.  Every other lane
+// starts W = 96 rows above its segment from a guess (state 0): tracebacks from any state merge with the survivor path within a
+// few constraint lengths, and a guess is never trusted: a lane records the state it had when it entered its segment and the
+// one it left it with, and while some lane's entry state differs from what the lane above it really ended with, those lanes walk
+// their segment again from that state.  Lane 0 is exact, so each round makes at least one more lane exact; the walk is a
+// deterministic function of (row, state), so when no lane differs the bytes are those of the reference's single walk.
+// (The same idea as the segment-parallel chainback of the K >= 15 codes in chainback_spec.hip, inside one wave.)
+// Short frames, ragged top bits and unaligned outputs take the reference's bit-at-a-time form.
 struct CbArgs {
     const unsigned long long *dec;
     int cap_rows, rows_written, nframes;
@@ -266,6 +273,8 @@ struct CbArgs {
     size_t data_stride;
     unsigned nbits, endstate;
 };
+
+constexpr int SEG_UNIT = 96, SEG_WARM = 96, SEG_BATCH = 24;  // rows fetched per lane and round trip: 24 (four periods)
 
 __global__ __launch_bounds__(64) void chainback_wave_kernel(CbArgs a) {
     constexpr int add = 2;  // ADDSHIFT = 8 - (K-1)                                    spiral47.cpp:92-101
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(64) void chainback_wave_kernel(CbArgs a) {
     unsigned e = (a.endstate % N) << add;
     int rot = (int)(a.nbits % NB);  // (r + 1) mod 6 at the first row visited, r = nbits - 1 + 6
 
-    auto slow = [&](unsigned i) {  // decoded bit i from row i + 6
+    auto slow = [&](unsigned i) {  // decoded bit i from row i + 6, every lane the same walk
         const long r = (long)i + NB;
         const unsigned st = e >> add;
         const unsigned p = rot == 0 ? st : (((st >> rot) | (st << (NB - rot))) & (N - 1u));
@@ -288,52 +297,65 @@ __global__ __launch_bounds__(64) void chainback_wave_kernel(CbArgs a) {
     };
 
     unsigned i = a.nbits;
-    while (i > 0 && (long)(i - 1) + NB >= a.rows_written) slow(--i);
-    const bool out_aligned = ((reinterpret_cast<uintptr_t>(a.data) | a.data_stride) & 3) == 0;
-    if (out_aligned) {
-        while (i > 0 && (i & 63u)) slow(--i);  // chunks of 64 rows end on a dword of the output
-        if (i >= 64u) {
-            auto pos = [&]() {
-                const unsigned st = e >> add;
-                return rot == 0 ? st : (((st >> rot) | (st << (NB - rot))) & (N - 1u));
-            };
-            unsigned q = pos();
-            unsigned h = e << 24;  // the last 32 decisions, newest on top: its top byte is the reference's register
-            unsigned long long cur = rows[(long)(i - 64u) + NB + lane];  // lane l: row of decoded bit i - 64 + l
-            while (i >= 64u) {
-                const unsigned long long mine = cur;
-                if (i >= 128u) cur = rows[(long)(i - 128u) + NB + lane];
-                const unsigned mlo = (unsigned)mine, mhi = (unsigned)(mine >> 32);
-                // 64 bits, newest first: bit i - 1 - d is in lane 63 - d; rot at that row = (rot0 - d) mod 6
-                auto walk = [&](auto R0) {
-                    constexpr int ROT0 = decltype(R0)::value;
-                    sfor<64>([&](auto D) {
-                        constexpr int d = decltype(D)::value;
-                        constexpr int rotd = ((ROT0 - d) % NB + NB) % NB, jb = (NB - rotd) % NB;
-                        const unsigned wlo = (unsigned)__builtin_amdgcn_readlane((int)mlo, 63 - d);
-                        const unsigned whi = (unsigned)__builtin_amdgcn_readlane((int)mhi, 63 - d);
-                        const unsigned t = (unsigned)((((unsigned long long)whi << 32) | wlo) >> q);
-                        q = (q & ~(1u << jb)) | ((t << jb) & (1u << jb));
-                        h = (h >> 1) | (t << 31);
-                        if constexpr (d == 31 || d == 63) {
-                            // h = decisions of bits i-32 .. i-1 (d == 31) or i-64 .. i-33: four output bytes, first byte on top
-                            if (lane == 0) *reinterpret_cast<unsigned *>(out + ((i - 1u - d) >> 3)) = __builtin_bswap32(h);
-                        }
-                    });
-                };
-                switch (rot) {  // uniform
-                case 0: walk(std::integral_constant<int, 0>{}); break;
-                case 1: walk(std::integral_constant<int, 1>{}); break;
-                case 2: walk(std::integral_constant<int, 2>{}); break;
-                case 3: walk(std::integral_constant<int, 3>{}); break;
-                case 4: walk(std::integral_constant<int, 4>{}); break;
-                default: walk(std::integral_constant<int, 5>{}); break;
+    const bool out_aligned = (reinterpret_cast<uintptr_t>(out) & 3) == 0;  // this frame's bytes (dword stores)
+    if (out_aligned && a.nbits >= 2u * SEG_UNIT) {
+        while (i & 31u) slow(--i);  // the ragged top: segments are whole dwords of the output
+        const unsigned nb0 = i;
+        const unsigned S = SEG_UNIT * ((nb0 + SEG_UNIT * 64u - 1u) / (SEG_UNIT * 64u));  // at most 64 segments
+        const long hi = (long)nb0 - (long)lane * S;            // this lane decodes bits [lo, hi)
+        const long lo = hi - (long)S > 0 ? hi - (long)S : 0;
+        const bool active = hi > 0;
+        // position of the exact state at bit nb0 - 1
+        const unsigned st0 = e >> add;
+        const unsigned q_exact = rot == 0 ? st0 : (((st0 >> rot) | (st0 << (NB - rot))) & (N - 1u));
+        const int rot0 = rot;  // phase of loop step 0 of every (re-)walk: all segment tops are congruent mod 6
+        // lanes whose warm-up would start above bit nb0 - 1 start AT it, with the exact state
+        const bool from_top = hi + SEG_WARM > (long)nb0;
+        unsigned q = from_top ? q_exact : 0u;
+        unsigned q_in = q, q_out = 0u, h = e << 24;
+
+        // steps [g_lo, g_hi) of the walk that starts W rows above the segment: bit index hi + W - 1 - g for this lane
+        auto walk = [&](int g_lo, int g_hi, bool emit, bool enabled) {
+            for (int g0 = g_lo; g0 < g_hi; g0 += SEG_BATCH) {
+                unsigned long long w[SEG_BATCH];
+#pragma unroll
+                for (int d = 0; d < SEG_BATCH; d++) {
+                    const long bi = hi + SEG_WARM - 1 - (g0 + d);
+                    const long r = bi + NB;
+                    const bool ok = enabled && bi >= lo && bi < (long)nb0 && r < a.rows_written;
+                    w[d] = ok ? rows[ok ? r : 0] : 0ull;
                 }
-                rot = (rot + NB * 11 - 64) % NB;
-                i -= 64u;
+                // jb of step g: (6 - rot_g) mod 6 with rot_g = (rot0 - g) mod 6; SEG_BATCH and SEG_WARM are multiples of 6
+                sfor<SEG_BATCH>([&](auto D) {
+                    constexpr int d = decltype(D)::value;
+                    const long bi = hi + SEG_WARM - 1 - (g0 + d);
+                    const bool ok = enabled && bi >= lo && bi < (long)nb0;
+                    const int jb = (NB - ((rot0 - d) % NB + NB) % NB) % NB;  // uniform; g0 is a multiple of 6
+                    const unsigned tt = (unsigned)(w[d] >> q);
+                    const unsigned nq = (q & ~(1u << jb)) | ((tt & 1u) << jb);
+                    const unsigned nh = (h >> 1) | (tt << 31);
+                    q = ok ? nq : q;
+                    h = ok ? nh : h;
+                    if (emit && ok && (bi & 31) == 0) *reinterpret_cast<unsigned *>(out + (bi >> 3)) = __builtin_bswap32(h);
+                });
             }
-            e = h >> 24;
+        };
+        walk(0, SEG_WARM, false, active);
+        q_in = q;
+        walk(SEG_WARM, SEG_WARM + (int)S, true, active);
+        q_out = q;
+        // verify from the top down: lane l entered with q_in, the lane above left with q_out
+        for (int round = 0; round < 64; round++) {
+            unsigned above = (unsigned)__shfl_up((int)q_out, 1);
+            const bool redo = active && lane > 0 && !from_top && q_in != above;
+            if (__builtin_amdgcn_ballot_w64(redo) == 0ull) break;
+            q = above;
+            q_in = redo ? above : q_in;
+            const unsigned keep = q_out;
+            walk(SEG_WARM, SEG_WARM + (int)S, true, redo);
+            q_out = redo ? q : keep;
         }
+        return;
     }
     while (i > 0) slow(--i);
 }

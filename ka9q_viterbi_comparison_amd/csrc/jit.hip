@@ -68,7 +68,7 @@ std::string compiler() {
     return root + "/bin/hipcc";
 }
 
-constexpr unsigned long long FNV_BASIS = 1469598103934665603ull, FNV_PRIME = 1099511628211ull;
+constexpr unsigned long long FNV_BASIS = 0xCBF29CE484222325ull, FNV_PRIME = 0x100000001B3ull;  // as tools/kernel_hash.py
 unsigned long long fnv1a(const void *data, size_t n, unsigned long long h) {
     const unsigned char *p = static_cast<const unsigned char *>(data);
     for (size_t i = 0; i < n; i++) {
@@ -207,6 +207,17 @@ int run_compiler(const std::vector<std::string> &argv, const std::string &log) {
 
 }  // namespace
 
+// 1: the kernel sources next to the library are the ones it was built from; 0: they differ (run-time builds refused); -1: unreadable
+int jit_sources_match(std::string *why) {
+    unsigned long long h = 0;
+    if (!sources_fingerprint(source_dir(), &h, why)) return -1;
+    if (h != VH_JIT_SOURCES_HASH) {
+        *why = "the kernel sources in " + source_dir() + " are not the ones this library was built from (edited without a rebuild?)";
+        return 0;
+    }
+    return 1;
+}
+
 bool jit_enabled() {
     const char *e = getenv("VHIP_JIT");
     return !(e && e[0] == '0');
@@ -217,12 +228,11 @@ bool jit_enabled() {
 bool jit_function(const char *src, const std::vector<std::string> &defs, const char *kname, hipFunction_t *fn, std::string *err) {
     const std::string dir = source_dir(), cc = compiler();
     const std::string path = dir + "/" + src;
-    unsigned long long srch = 0;
-    if (!sources_fingerprint(dir, &srch, err)) return false;
-    if (srch != VH_JIT_SOURCES_HASH) {
-        *err = "the kernel sources in " + dir + " are not the ones this library was built from (edited without a rebuild?): run-time builds refused";
+    if (jit_sources_match(err) != 1) {
+        *err += ": run-time builds refused";
         return false;
     }
+    const unsigned long long srch = VH_JIT_SOURCES_HASH;
     if (access(cc.c_str(), X_OK) != 0) {
         *err = "runtime specialisation needs hipcc (" + cc + " is not executable; set VHIP_HIPCC or ROCM_PATH)";
         return false;

@@ -176,6 +176,7 @@ hipError_t launch_k24t_pass(int pass, const int16_t *oldm, int16_t *newm, unsign
 
 // ---------------------------------------------------------------- jit.hip (fast kernels for other polynomials)
 bool jit_enabled();  // VHIP_JIT=0 turns the runtime specialisation off
+int jit_sources_match(std::string *why);  // 1 / 0 / -1 (unreadable): the sources next to the library vs the fingerprint baked into it
 // defs: one compiler argument each (no shell is involved)
 bool jit_function(const char *src, const std::vector<std::string> &defs, const char *kname, hipFunction_t *fn, std::string *err);
 std::string jit_poly_define(const int *poly, int n);

@@ -122,7 +122,10 @@ namespace {
 // one handle: 1.92 -> 2.07 ms per frame), where the write-back is hidden behind the other decodes' passes.
 constexpr int K24_WORKERS_MIN_PLAIN = 3;
 // K=7 handles with at most this many frames take the one-wave-per-frame kernel (tools/small_batch_probe.py)
-constexpr int WAVE_MAX_FRAMES = 64;
+// (tools/small_batch_probe.py, 2054-step frames, update + chainback in ms.  ka9q27: 2048 frames 0.31 + 0.08 against 0.37 + 0.19 for
+// the register kernel, 4096 frames 0.60 + 0.12 against 0.37 + 0.19.  spiral47, whose every step also forms the wave minimum
+// (spiral47.cpp:313-331): 1024 frames 0.43 + 0.06 against 0.54 + 0.17, 2048 frames 0.85 + 0.08 against 0.55 + 0.19)
+constexpr int WAVE_MAX_FRAMES_MOD = 2048, WAVE_MAX_FRAMES_SAT = 1024;
 
 // vhip_status(): -1 after a failed init / update / chainback on the handle, 0 after a successful one.  The reference ABI
 // returns void from update and a path metric (any int) from chainback_viterbi615, so the return value alone cannot
@@ -288,7 +291,8 @@ int auto_variant(const vhip_decoder *p) {
     // K=7 with few frames: one wave per frame, one state per lane -- a frame is a chain of dependent steps and this geometry
     // issues the fewest instructions per step (acs_wave.hip; 8198-step frame: 0.2 ms against 1.5 ms for the register kernel,
     // which catches up once its 16-64 frames per wave are all in use)
-    if (p->K == 7 && vh::wave_code_supported(p->code) && p->nframes <= WAVE_MAX_FRAMES) return VHIP_VARIANT_WAVE;
+    if (p->K == 7 && vh::wave_code_supported(p->code) && p->nframes <= (p->code == VHIP_KA9Q27 ? WAVE_MAX_FRAMES_MOD : WAVE_MAX_FRAMES_SAT))
+        return VHIP_VARIANT_WAVE;
     if (p->K <= 9 && vh::regs_poly_supported(p->code, p->poly)) {
         // K=9 r=1/2 with few frames: one workgroup per frame (256 lanes = 256 states) finishes a 2054-step frame in
         // 0.33 ms, the register kernel (4 lanes per frame, one wave for 16 frames) in 1.09 ms, and the two meet near
@@ -1126,6 +1130,12 @@ int vhip_chainback_rewalked(vhip_decoder *p, int *nseg) {
 
 // ---------------------------------------------------------------- fused sliding-window decode
 int vhip_is_runtime_specialised(const vhip_decoder *p) { return p ? (p->jit ? 1 : 0) : -1; }
+int vhip_runtime_build_sources_ok(void) {
+    std::string why;
+    const int rc = vh::jit_sources_match(&why);
+    if (rc != 1) g_last_error = "viterbi_hip: " + why;
+    return rc;
+}
 
 namespace {
 bool window_params(const vhip_decoder *p, int *depth, int *block) {

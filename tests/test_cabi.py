@@ -62,6 +62,8 @@ def test_jit_fingerprint_matches_the_sources():
     names = ["acs_regs.hip", "acs_k15.hip", "acs_k24t.hip", "kernels.h", "viterbi_codes.h", "k24t_layout.h", "k15_layout.h"]
     baked = re.search(r"VH_JIT_SOURCES_HASH 0x([0-9a-f]+)ull", open(os.path.join(csrc, "jit_sources_hash.h")).read()).group(1)
     assert int(baked, 16) == fnv1a64_of_files([os.path.join(csrc, n) for n in names])
+    # ... and the library, hashing the files itself, agrees (this caught a mistyped FNV basis that refused every run-time build)
+    assert _lib.load().vhip_runtime_build_sources_ok() == 1, _lib.last_error()
     # the same list, in the same order, on both sides
     assert all(n in open(os.path.join(csrc, "jit.hip")).read() for n in names)
 

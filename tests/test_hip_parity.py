@@ -781,3 +781,44 @@ def test_segment_parallel_chainback(name, variant, nframes, B):
     for o in oracles:
         o.close()
     dec.close()
+
+
+@pytest.mark.parametrize("name", ["27", "47", "spiral27"])
+def test_wave_variant_long_frames_and_segmented_chainback(name):
+    """The one-wave-per-frame kernels (acs_wave.hip) on frames long enough for every path: whole 48-step blocks through the LDS
+    branch-metric table over several table chunks, the steps in front of and behind them (incremental updates that start
+    at every phase of the six-row period), and the chainback that cuts a frame into segments walked by the 64 lanes at once,
+    verified from the top and re-walked where a lane's guessed entry state was wrong -- on pure-noise symbols (tracebacks
+    merge late, if at all, so re-walks do happen), AWGN frames and ragged bit counts / end states.  Rows, metrics and bytes
+    against the oracle."""
+    spec = C.CODES[name]
+    code = spec.code
+    rng = np.random.default_rng(77 + code)
+    for B, nframes, kind in ((1024, 2, "awgn"), (300, 3, "noise"), (701, 2, "awgn"), (130, 5, "noise")):
+        steps = B * 8 + spec.K - 1
+        steps -= 0 if spec_is_incremental(code) else steps % 2
+        if kind == "awgn":
+            _, syms = frames(code, 31 + B, nframes, B, spec.ebn0_db - 2.0)
+            syms = np.ascontiguousarray(syms[:, :steps * spec.R])
+        else:
+            syms = rng.integers(0, 256, size=(nframes, steps * spec.R), dtype=np.uint8)
+        dec = HipViterbi(name, steps, nframes=nframes, variant=VARIANT_WAVE)
+        dec.reset()
+        if spec_is_incremental(code):
+            # three calls: the second starts at row 1000 + phase, the third wherever that leaves it
+            cut1 = min(steps - 2, 1000 + (B % 6))
+            cut2 = min(steps - 1, cut1 + 53)
+            for lo, hi in ((0, cut1), (cut1, cut2), (cut2, steps)):
+                dec.update(np.ascontiguousarray(syms[:, lo * spec.R:hi * spec.R]), nbits=hi - lo)
+        else:
+            dec.update(syms, nbits=steps)
+        for nbits, endstate in ((B * 8, 0), (B * 8 - 13, 37), (B * 8 - 32, 5)):
+            data, _ = dec.chainback(nbits, endstate)
+            for f in range(nframes):
+                ref = oracle_decode(code, syms[f], steps, nbits, endstate=endstate)
+                assert np.array_equal(data[f], ref["data"]), (name, B, kind, nbits, f)
+        for f in range(nframes):
+            ref = oracle_decode(code, syms[f], steps, B * 8)
+            assert np.array_equal(dec.decision_rows(f, 0, steps), ref["rows"]), (name, B, kind, f)
+            assert np.array_equal(dec.metrics(f), ref["metrics"]), (name, B, kind, f)
+        dec.close()
