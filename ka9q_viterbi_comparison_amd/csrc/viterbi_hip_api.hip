@@ -298,6 +298,8 @@ int auto_variant(const vhip_decoder *p) {
         // 0.33 ms, the register kernel (4 lanes per frame, one wave for 16 frames) in 1.09 ms, and the two meet near
         // 3000 frames (tools/small_batch_probe.py); for the other K <= 9 codes the register kernels win or tie everywhere
         if (p->K == 9 && p->R == 2 && p->nframes <= 2048) return VHIP_VARIANT_LDS;
+        // r=1/4 (spiral49, whose every step also forms the workgroup minimum): 0.91-1.07 ms against 1.35-1.37 ms up to 1024 frames
+        if (p->K == 9 && p->R == 4 && p->nframes <= 1024) return VHIP_VARIANT_LDS;
         return VHIP_VARIANT_REGS;
     }
     if ((p->code == VHIP_KA9Q615 || p->code == VHIP_SPIRAL615) && vh::k15_poly_supported(p->poly)) return VHIP_VARIANT_REGS;

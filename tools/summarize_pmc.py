@@ -2,7 +2,9 @@
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs (collected in SEPARATE passes, as MI355X_MICROARCH.md
 §HBM prescribes) into profiles/traffic_<code>.json, which bench.py reads for roofline.traffic.
 
-    python tools/summarize_pmc.py <code> <fetch_counter_collection.csv> <write_counter_collection.csv> <kernel substring>
+    python tools/summarize_pmc.py <code> <fetch_counter_collection.csv> <write_counter_collection.csv> <kernel substring> [name]
+
+(name: file stem, default <code>; e.g. 615_chainback for the chainback kernel of the K=15 run)
 
 Units and corrections (MI355X_MICROARCH.md §HBM): the counters are in KiB; on gfx950 FETCH_SIZE reports half of the
 bytes of a wide coalesced read, so it is doubled; WRITE_SIZE is exact for streaming stores."""
@@ -23,6 +25,7 @@ def mean_counter(path, kernel_sub, counter):
 
 def main():
     code, fetch_csv, write_csv, ksub = sys.argv[1:5]
+    name = sys.argv[5] if len(sys.argv) > 5 else code
     if code == "224":
         # K=24: one update is many pass launches.  Mean counters of the full-pass kernels of each kind (H: 9 steps, L: 14
         # steps), added up per 23-step period and scaled to the bench's 2071-step update.
@@ -51,7 +54,7 @@ def main():
         "note": "separate --pmc passes; FETCH_SIZE x2 (gfx950 half-count of wide reads), WRITE_SIZE exact; KiB -> bytes",
     }
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(os.environ.get("PROFILES_DIR", os.path.join(root, "profiles")), f"traffic_{code}.json")
+    path = os.path.join(os.environ.get("PROFILES_DIR", os.path.join(root, "profiles")), f"traffic_{name}.json")
     json.dump(out, open(path, "w"), indent=1)
     print(path, out)
 

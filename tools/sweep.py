@@ -12,14 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_sweep"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_sweep"))
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--cpu", action="store_true", help="also time the CPU baseline per code (adds ~12 s each)")
     ap.add_argument("--codes", default="27,47,29,49,615,224,spiral27,spiral29,spiral615")
     args = ap.parse_args()
     lines = []
     for code in args.codes.split(","):
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--code", code, "--steps", str(args.steps), "--warmup", "3"]
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--code", code, "--steps", str(args.steps), "--warmup", "3", "--no-extra-configs"]
         if not args.cpu:
             cmd.append("--no-cpu-baseline")
         r = subprocess.run(cmd, capture_output=True, text=True)
