@@ -168,20 +168,34 @@ hipError_t launch_acs_lds(int code, const AcsLdsArgs &a, hipStream_t stream) {
 }
 
 // ---- init: fill path metrics (init_viterbi27_sse2 viterbi27_sse2.cpp:42-54 and siblings) -------------
-__global__ void init_metrics_kernel(int16_t *metrics, size_t n_per_frame, int nframes, int init_all, int init_start,
-                                    unsigned start_state) {
-    const size_t total = n_per_frame * (size_t)nframes;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t st = i % n_per_frame;
-        metrics[i] = (int16_t)(st == start_state ? init_start : init_all);
+// n_per_frame is 2^(K-1) >= 64: a thread writes eight consecutive metrics (16 bytes) of one frame, the state index is a mask,
+// and only the vector that holds the start state differs from the fill value.  (The first version took a 64-bit modulo per
+// 2-byte store; on a 4096-frame K=15 handle that was 1.7-3.9 ms per decode of VALU work beside the update kernel --
+// profiles/r03_viterbi615_kernel_stats.csv -- for a 134 MB fill.)
+__global__ __launch_bounds__(256) void init_metrics_kernel(int16_t *metrics, unsigned n_mask, size_t total8, int init_all, int init_start,
+                                                           unsigned start_state) {
+    const unsigned short a = (unsigned short)init_all, s = (unsigned short)init_start;
+    const unsigned aa = a | ((unsigned)a << 16);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned st0 = (unsigned)(i * 8) & n_mask;  // state of the first of the eight
+        uint4 v = make_uint4(aa, aa, aa, aa);
+        if ((start_state & ~7u) == st0) {
+            unsigned short e[8] = {a, a, a, a, a, a, a, a};
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if ((start_state & 7u) == (unsigned)k) e[k] = s;
+            v = make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16), e[6] | ((unsigned)e[7] << 16));
+        }
+        reinterpret_cast<uint4 *>(metrics)[i] = v;
     }
 }
 
 hipError_t launch_init_metrics(int16_t *metrics, size_t n_per_frame, int nframes, int init_all, int init_start,
                                unsigned start_state, hipStream_t stream) {
-    const size_t total = n_per_frame * (size_t)nframes;
-    int blocks = (int)min((size_t)4096, (total + 255) / 256);
-    hipLaunchKernelGGL(init_metrics_kernel, dim3(blocks), dim3(256), 0, stream, metrics, n_per_frame, nframes, init_all,
+    if (n_per_frame < 8 || (n_per_frame & (n_per_frame - 1)) != 0) return hipErrorInvalidValue;  // 2^(K-1) states
+    const size_t total8 = n_per_frame * (size_t)nframes / 8;
+    const int blocks = (int)min((size_t)4096, (total8 + 255) / 256);
+    hipLaunchKernelGGL(init_metrics_kernel, dim3(blocks), dim3(256), 0, stream, metrics, (unsigned)(n_per_frame - 1), total8, init_all,
                        init_start, start_state);
     return hipGetLastError();
 }

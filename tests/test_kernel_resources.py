@@ -31,6 +31,9 @@ def kernel_metadata(source):
 @pytest.mark.parametrize("source,pattern,min_kernels", [
     ("acs_k15.hip", r"acs_k15_kernel|decode_windowed_k15_kernel", 4),
     ("acs_k24t.hip", r"acs_k24t_pass_[hl]_kernelILb[01]ELi0E", 4),
+    # the latency kernels park rows / row batches in registers indexed at compile time: an indexed access would put them into scratch
+    ("acs_wave.hip", r"acs_wave_kernel|chainback_wave_kernel", 4),
+    ("chainback.hip", r"chainback_rows_seg_kernel", 2),
 ])
 def test_production_kernels_do_not_spill(source, pattern, min_kernels):
     meta = {k: v for k, v in kernel_metadata(source).items() if re.search(pattern, k)}
