@@ -91,12 +91,10 @@ __device__ __forceinline__ unsigned to_lane_metric(int m) {
     else return (((unsigned)m & 255u) << 24) | 0x00ffffffu;
 }
 
-// One trellis step at phase PHI.  tv / tcv: the butterfly's branch metrics t and t' in the top byte.  up: this lane holds
-// old[j + H] (position bit 5 - PHI set).  Returns the decision of the new state that now lives in this lane.
-template <class C, int PHI>
-__device__ __forceinline__ bool step(unsigned &M, unsigned tv, unsigned tcv, bool up, unsigned lane) {
-    constexpr int B = NB - 1 - PHI;
-    const unsigned X = partner<B>(M, lane);
+// Add-compare-select of one lane.  M: this lane's metric, X: its butterfly partner's, tv / tcv: the butterfly's branch metrics
+// t and t' in the top byte, up: this lane holds old[j + H].  Returns the decision of the new state that now lives in this lane.
+template <class C>
+__device__ __forceinline__ bool acs(unsigned &M, unsigned X, unsigned tv, unsigned tcv, bool up) {
     if constexpr (C::metric == U8MOD) {
         // lower position: m0 = old[j] + t (self), m1 = old[j+H] + t' (partner); upper position: m2 = old[j] + t' (partner),
         // m3 = old[j+H] + t (self)                                                       viterbi27_sse2.cpp:149-152
@@ -114,6 +112,11 @@ __device__ __forceinline__ bool step(unsigned &M, unsigned tv, unsigned tcv, boo
         M = min(cs, co);
         return d;
     }
+}
+// One trellis step of the K=7 kernel at phase PHI: the partner is lane ^ (1 << (5 - PHI)).
+template <class C, int PHI>
+__device__ __forceinline__ bool step(unsigned &M, unsigned tv, unsigned tcv, bool up, unsigned lane) {
+    return acs<C>(M, partner<NB - 1 - PHI>(M, lane), tv, tcv, up);
 }
 
 // spiral47.cpp:313-331: after every step, if new[0] > threshold, subtract the minimum over all states (saturating; nothing
@@ -251,6 +254,134 @@ __global__ __launch_bounds__(THREADS) void acs_wave_kernel(Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- K = 9: four waves per frame
+// 256 states = 4 waves x 64 lanes, position p = wave * 64 + lane in the same rotating layout (period 8).  Phases 2..7 pair the six
+// lane bits: exactly the K=7 step above, per wave, no LDS, no barrier.  Phases 0 and 1 pair the two wave bits: the partner is
+// the same lane of wave ^ 2 / wave ^ 1, fetched through a 1 KiB LDS exchange (one barrier; two buffers alternate so that nobody
+// waits twice).  All four waves work, so they fill the branch-metric table of a chunk themselves (1-5 % of a chunk's
+// instructions).  spiral49 (spiral49.cpp:790, 1490: after EVERY step, if new[0] > 103 subtract the minimum over all 256 states):
+// each wave forms its minimum, wave 0 adds the verdict on state 0, and one barrier per step carries both through LDS.
+// Decisions: [frame][row][wave] 64-bit ballots = 32 bytes per row, bit (p & 63) of word (p >> 6).
+namespace k9 {
+constexpr int K = 9, NB = 8;
+constexpr unsigned N = 256, H = 128;
+__host__ __device__ constexpr unsigned rotl8(unsigned x, int s) {
+    s %= NB;
+    return s == 0 ? x : (((x << s) | (x >> (NB - s))) & (N - 1u));
+}
+}  // namespace k9
+
+template <class C>
+__global__ __launch_bounds__(256) void acs_wave9_kernel(Args a) {
+    using namespace k9;
+    constexpr int R = C::R, NC = 1 << R;
+    constexpr int STEP_BYTES = NC * 8;
+    constexpr int CH = (TBL_BYTES / STEP_BYTES / BLK) * BLK;
+    static_assert(BLK % k9::NB == 0 && CH >= BLK, "a block is whole periods");
+    __shared__ __attribute__((aligned(16))) unsigned char tbl[TBL_BYTES];
+    __shared__ unsigned xchg[2][4][64];   // wave-bit phases: every wave's metrics, buffer = phase
+    __shared__ unsigned red[2][8];        // spiral: per-wave minima [0..3], wave 0's "new[0] > threshold" [4]; buffer = step parity
+
+    const int f = blockIdx.x;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned char *syms = a.syms + (size_t)f * a.sym_stride;
+    unsigned long long *rows = a.dec + ((size_t)f * a.cap_rows + a.row0) * 4 + wave;  // this wave's column; row stride 4 words
+    const int phi0 = a.row0 % k9::NB;
+    const int pre = min(a.nsteps, (k9::NB - phi0) % k9::NB);
+    const int nmain = ((a.nsteps - pre) / BLK) * BLK;
+    const int nchunks = (nmain + CH - 1) / CH;
+
+    unsigned cls[k9::NB], aoff[k9::NB];
+    bool up[k9::NB];
+#pragma unroll
+    for (int p = 0; p < k9::NB; p++) {
+        const unsigned st = rotl8(tid, p);  // old state held at phase p
+        cls[p] = bt_class<R>(st & (k9::H - 1u), a.poly);
+        up[p] = (st >> (k9::NB - 1)) & 1u;
+        aoff[p] = cls[p] * 8u;
+    }
+    unsigned M = to_lane_metric<C>(a.metrics[(size_t)f * k9::N + rotl8(tid, phi0)]);
+    int parity = 0;  // of the step, for the renormalisation buffers
+
+    // partner of this lane at phase PHI (uniform): lane bits through the K=7 partner fetch, wave bits through LDS
+    auto fetch = [&](auto P) -> unsigned {
+        constexpr int PHI = decltype(P)::value;
+        if constexpr (PHI >= 2) {
+            return partner<k9::NB - 1 - PHI>(M, lane);
+        } else {
+            xchg[PHI][wave][lane] = M;
+            __syncthreads();
+            return xchg[PHI][wave ^ (PHI == 0 ? 2u : 1u)][lane];
+        }
+    };
+    auto renorm = [&]() {
+        if constexpr (C::renorm) {
+            const unsigned mn = wave_min_u32(M);
+            if (lane == 0) {
+                red[parity][wave] = mn;
+                if (wave == 0) red[parity][4] = M > (((unsigned)C::renorm_thr << 24) | 0x00ffffffu);  // state 0 = position 0
+            }
+            __syncthreads();
+            const unsigned *rd = red[parity];
+            if (rd[4]) M -= min(min(rd[0], rd[1]), min(rd[2], rd[3])) & 0xff000000u;
+            parity ^= 1;
+        }
+    };
+    auto slow_step = [&](int i) {
+        int s[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) s[r] = syms[(size_t)i * R + r];
+        const int phi = (a.row0 + i) % k9::NB;
+        bool d = false;
+        sfor<k9::NB>([&](auto P) {
+            constexpr int PHI = decltype(P)::value;
+            if (phi == PHI) {  // uniform
+                const int t = C::bm(s, cls[PHI]);
+                const unsigned X = fetch(P);
+                d = acs<C>(M, X, (unsigned)t << 24, (unsigned)C::bm_tc(t) << 24, up[PHI]);
+            }
+        });
+        renorm();
+        const unsigned long long row = __builtin_amdgcn_ballot_w64(d);
+        if (lane == 0) rows[(size_t)i * 4] = row;
+    };
+
+    for (int i = 0; i < pre; i++) slow_step(i);
+    for (int c = 0; c < nchunks; c++) {
+        const int s0 = pre + c * CH, cnt = min(CH, nmain - c * CH);
+        __syncthreads();  // everybody is done with the previous chunk's table
+        for (int i = (int)tid; i < cnt; i += 256) {
+            int s[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) s[r] = syms[(size_t)(s0 + i) * R + r];
+            uint2 *e = reinterpret_cast<uint2 *>(&tbl[i * STEP_BYTES]);
+#pragma unroll
+            for (int cl = 0; cl < NC; cl++) {
+                const int t = C::bm(s, (unsigned)cl);
+                e[cl] = make_uint2((unsigned)t << 24, (unsigned)C::bm_tc(t) << 24);
+            }
+        }
+        __syncthreads();
+        for (int b0 = 0; b0 < cnt; b0 += BLK) {
+            unsigned acc_lo = 0, acc_hi = 0;
+            const unsigned char *blk = tbl + b0 * STEP_BYTES;
+            sfor<BLK>([&](auto J) {
+                constexpr int j = decltype(J)::value, PHI = j % k9::NB;
+                const uint2 e = *reinterpret_cast<const uint2 *>(blk + aoff[PHI] + j * STEP_BYTES);
+                const unsigned X = fetch(std::integral_constant<int, PHI>{});
+                const bool d = acs<C>(M, X, e.x, e.y, up[PHI]);
+                renorm();
+                const unsigned long long row = __builtin_amdgcn_ballot_w64(d);
+                acc_lo = writelane<j>(acc_lo, (unsigned)row);
+                acc_hi = writelane<j>(acc_hi, (unsigned)(row >> 32));
+            });
+            if (lane < (unsigned)BLK) rows[(size_t)(s0 + b0 + (int)lane) * 4] = ((unsigned long long)acc_hi << 32) | acc_lo;
+        }
+    }
+    for (int i = pre + nmain; i < a.nsteps; i++) slow_step(i);
+    a.metrics[(size_t)f * k9::N + rotl8(tid, (a.row0 + a.nsteps) % k9::NB)] = (int16_t)(M >> 24);
+}
+
 // ---------------------------------------------------------------------------------------------------- chainback
 // chainback_viterbi27_sse2 (viterbi27_sse2.cpp:78-105) / chainback_spiral47 (spiral47.cpp:84-121) over position-ordered rows:
 // one wave per frame.  The walk runs in position space (chainback_k7_lds_kernel in acs_regs.hip explains it): p =
@@ -274,31 +405,37 @@ struct CbArgs {
     unsigned nbits, endstate;
 };
 
-constexpr int SEG_UNIT = 96, SEG_WARM = 96, SEG_BATCH = 24;  // rows fetched per lane and round trip: 24 (four periods)
-
+// KK = 7: one 64-bit word per row, segments of 96 bits (lcm of 32 output bits and 6 phases), 96 warm-up rows, 24 rows per round
+// trip.  KK = 9 (acs_wave9_kernel below): four words per row (word = position >> 6), segments of 32 bits, 128 warm-up rows, 8 rows
+// per round trip.
+template <int KK>
 __global__ __launch_bounds__(64) void chainback_wave_kernel(CbArgs a) {
-    constexpr int add = 2;  // ADDSHIFT = 8 - (K-1)                                    spiral47.cpp:92-101
+    constexpr int NBK = KK - 1, WORDS = (1 << NBK) / 64;
+    constexpr unsigned NK = 1u << NBK;
+    constexpr int add = (NBK < 8) ? 8 - NBK : 0;  // ADDSHIFT                         spiral47.cpp:92-101
+    constexpr int SEG_UNIT = KK == 7 ? 96 : 32, SEG_WARM = KK == 7 ? 96 : 128, SEG_BATCH = KK == 7 ? 24 : 8;
+    static_assert(KK - 2 + add == 7 && SEG_UNIT % 32 == 0 && SEG_UNIT % NBK == 0 && SEG_WARM % SEG_BATCH == 0 && SEG_BATCH % NBK == 0 && SEG_UNIT % SEG_BATCH == 0, "geometry");
     const int f = blockIdx.x;
     const unsigned lane = threadIdx.x;
-    const unsigned long long *rows = a.dec + (size_t)f * a.cap_rows;
+    const unsigned long long *rows = a.dec + (size_t)f * a.cap_rows * WORDS;
     unsigned char *out = a.data + (size_t)f * a.data_stride;
-    unsigned e = (a.endstate % N) << add;
-    int rot = (int)(a.nbits % NB);  // (r + 1) mod 6 at the first row visited, r = nbits - 1 + 6
+    unsigned e = (a.endstate % NK) << add;
+    int rot = (int)(a.nbits % NBK);  // (r + 1) mod NB at the first row visited, r = nbits - 1 + NB
 
-    auto slow = [&](unsigned i) {  // decoded bit i from row i + 6, every lane the same walk
-        const long r = (long)i + NB;
+    auto slow = [&](unsigned i) {  // decoded bit i from row i + NB, every lane the same walk
+        const long r = (long)i + NBK;
         const unsigned st = e >> add;
-        const unsigned p = rot == 0 ? st : (((st >> rot) | (st << (NB - rot))) & (N - 1u));
+        const unsigned p = rot == 0 ? st : (((st >> rot) | (st << (NBK - rot))) & (NK - 1u));
         unsigned k = 0;
-        if (r < a.rows_written) k = (unsigned)(rows[r] >> p) & 1u;
-        e = (e >> 1) | (k << (K - 2 + add));
+        if (r < a.rows_written) k = (unsigned)(rows[r * WORDS + (p >> 6)] >> (p & 63u)) & 1u;
+        e = (e >> 1) | (k << 7);
         if ((i & 7u) == 0 && lane == 0) out[i >> 3] = (unsigned char)e;
-        rot = rot == 0 ? NB - 1 : rot - 1;
+        rot = rot == 0 ? NBK - 1 : rot - 1;
     };
 
     unsigned i = a.nbits;
     const bool out_aligned = (reinterpret_cast<uintptr_t>(out) & 3) == 0;  // this frame's bytes (dword stores)
-    if (out_aligned && a.nbits >= 2u * SEG_UNIT) {
+    if (out_aligned && a.nbits >= 192u) {
         while (i & 31u) slow(--i);  // the ragged top: segments are whole dwords of the output
         const unsigned nb0 = i;
         const unsigned S = SEG_UNIT * ((nb0 + SEG_UNIT * 64u - 1u) / (SEG_UNIT * 64u));  // at most 64 segments
@@ -307,31 +444,44 @@ __global__ __launch_bounds__(64) void chainback_wave_kernel(CbArgs a) {
         const bool active = hi > 0;
         // position of the exact state at bit nb0 - 1
         const unsigned st0 = e >> add;
-        const unsigned q_exact = rot == 0 ? st0 : (((st0 >> rot) | (st0 << (NB - rot))) & (N - 1u));
-        const int rot0 = rot;  // phase of loop step 0 of every (re-)walk: all segment tops are congruent mod 6
+        const unsigned q_exact = rot == 0 ? st0 : (((st0 >> rot) | (st0 << (NBK - rot))) & (NK - 1u));
+        const int rot0 = rot;  // phase of loop step 0 of every (re-)walk: all segment tops are congruent mod NB
         // lanes whose warm-up would start above bit nb0 - 1 start AT it, with the exact state
         const bool from_top = hi + SEG_WARM > (long)nb0;
         unsigned q = from_top ? q_exact : 0u;
         unsigned q_in = q, q_out = 0u, h = e << 24;
 
         // steps [g_lo, g_hi) of the walk that starts W rows above the segment: bit index hi + W - 1 - g for this lane
-        auto walk = [&](int g_lo, int g_hi, bool emit, bool enabled) {
+        auto walk = [&](int g_lo, int g_hi, bool emit, bool enabled) __attribute__((always_inline)) {
             for (int g0 = g_lo; g0 < g_hi; g0 += SEG_BATCH) {
-                unsigned long long w[SEG_BATCH];
-#pragma unroll
-                for (int d = 0; d < SEG_BATCH; d++) {
+                unsigned long long w[SEG_BATCH][WORDS];
+                sfor<SEG_BATCH>([&](auto D) {
+                    constexpr int d = decltype(D)::value;
                     const long bi = hi + SEG_WARM - 1 - (g0 + d);
-                    const long r = bi + NB;
+                    const long r = bi + NBK;
                     const bool ok = enabled && bi >= lo && bi < (long)nb0 && r < a.rows_written;
-                    w[d] = ok ? rows[ok ? r : 0] : 0ull;
-                }
-                // jb of step g: (6 - rot_g) mod 6 with rot_g = (rot0 - g) mod 6; SEG_BATCH and SEG_WARM are multiples of 6
+                    const unsigned long long *rp = rows + (ok ? r : 0) * WORDS;
+                    if constexpr (WORDS == 1) {
+                        w[d][0] = ok ? rp[0] : 0ull;
+                    } else {
+                        const ulonglong2 v0 = reinterpret_cast<const ulonglong2 *>(rp)[0], v1 = reinterpret_cast<const ulonglong2 *>(rp)[1];
+                        w[d][0] = ok ? v0.x : 0ull; w[d][1] = ok ? v0.y : 0ull; w[d][2] = ok ? v1.x : 0ull; w[d][3] = ok ? v1.y : 0ull;
+                    }
+                });
+                // jb of step g: (NB - rot_g) mod NB with rot_g = (rot0 - g) mod NB; g0 is a multiple of NB
                 sfor<SEG_BATCH>([&](auto D) {
                     constexpr int d = decltype(D)::value;
                     const long bi = hi + SEG_WARM - 1 - (g0 + d);
                     const bool ok = enabled && bi >= lo && bi < (long)nb0;
-                    const int jb = (NB - ((rot0 - d) % NB + NB) % NB) % NB;  // uniform; g0 is a multiple of 6
-                    const unsigned tt = (unsigned)(w[d] >> q);
+                    const int jb = (NBK - ((rot0 - d) % NBK + NBK) % NBK) % NBK;  // uniform
+                    unsigned long long word;
+                    if constexpr (WORDS == 1) {
+                        word = w[d][0];
+                    } else {
+                        const unsigned long long a0 = (q & 64u) ? w[d][1] : w[d][0], a1 = (q & 64u) ? w[d][3] : w[d][2];
+                        word = (q & 128u) ? a1 : a0;
+                    }
+                    const unsigned tt = (unsigned)(word >> (q & 63u));
                     const unsigned nq = (q & ~(1u << jb)) | ((tt & 1u) << jb);
                     const unsigned nh = (h >> 1) | (tt << 31);
                     q = ok ? nq : q;
@@ -362,7 +512,9 @@ __global__ __launch_bounds__(64) void chainback_wave_kernel(CbArgs a) {
 
 }  // namespace wave7
 
-bool wave_code_supported(int code) { return code == VHIP_KA9Q27 || code == VHIP_SPIRAL47 || code == VHIP_SPIRAL27; }
+bool wave_code_supported(int code) {
+    return code == VHIP_KA9Q27 || code == VHIP_SPIRAL47 || code == VHIP_SPIRAL27 || code == VHIP_KA9Q29 || code == VHIP_SPIRAL49 || code == VHIP_SPIRAL29;
+}
 
 hipError_t launch_acs_wave(int code, const AcsLdsArgs &l, hipStream_t stream) {
     wave7::Args a;
@@ -379,6 +531,9 @@ hipError_t launch_acs_wave(int code, const AcsLdsArgs &l, hipStream_t stream) {
     case VHIP_KA9Q27: hipLaunchKernelGGL(wave7::acs_wave_kernel<Code27>, dim3(a.nframes), dim3(wave7::THREADS), 0, stream, a); break;
     case VHIP_SPIRAL47: hipLaunchKernelGGL(wave7::acs_wave_kernel<Code47>, dim3(a.nframes), dim3(wave7::THREADS), 0, stream, a); break;
     case VHIP_SPIRAL27: hipLaunchKernelGGL(wave7::acs_wave_kernel<CodeS27>, dim3(a.nframes), dim3(wave7::THREADS), 0, stream, a); break;
+    case VHIP_KA9Q29: hipLaunchKernelGGL(wave7::acs_wave9_kernel<Code29>, dim3(a.nframes), dim3(256), 0, stream, a); break;
+    case VHIP_SPIRAL49: hipLaunchKernelGGL(wave7::acs_wave9_kernel<Code49>, dim3(a.nframes), dim3(256), 0, stream, a); break;
+    case VHIP_SPIRAL29: hipLaunchKernelGGL(wave7::acs_wave9_kernel<CodeS29>, dim3(a.nframes), dim3(256), 0, stream, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -394,7 +549,9 @@ hipError_t launch_chainback_wave(const ChainbackRowsArgs &c, hipStream_t stream)
     a.data_stride = c.data_stride;
     a.nbits = c.nbits;
     a.endstate = c.endstate;
-    hipLaunchKernelGGL(wave7::chainback_wave_kernel, dim3(a.nframes), dim3(64), 0, stream, a);
+    if (c.K == 7) hipLaunchKernelGGL(wave7::chainback_wave_kernel<7>, dim3(a.nframes), dim3(64), 0, stream, a);
+    else if (c.K == 9) hipLaunchKernelGGL(wave7::chainback_wave_kernel<9>, dim3(a.nframes), dim3(64), 0, stream, a);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -126,6 +126,7 @@ constexpr int K24_WORKERS_MIN_PLAIN = 3;
 // the register kernel, 4096 frames 0.60 + 0.12 against 0.37 + 0.19.  spiral47, whose every step also forms the wave minimum
 // (spiral47.cpp:313-331): 1024 frames 0.43 + 0.06 against 0.54 + 0.17, 2048 frames 0.85 + 0.08 against 0.55 + 0.19)
 constexpr int WAVE_MAX_FRAMES_MOD = 2048, WAVE_MAX_FRAMES_SAT = 1024;
+constexpr int WAVE9_MAX_FRAMES_MOD = 256, WAVE9_MAX_FRAMES_SAT = 256;  // K=9 (to be replaced by the measured crossover)
 
 // vhip_status(): -1 after a failed init / update / chainback on the handle, 0 after a successful one.  The reference ABI
 // returns void from update and a path metric (any int) from chainback_viterbi615, so the return value alone cannot
@@ -292,6 +293,9 @@ int auto_variant(const vhip_decoder *p) {
     // issues the fewest instructions per step (acs_wave.hip; 8198-step frame: 0.2 ms against 1.5 ms for the register kernel,
     // which catches up once its 16-64 frames per wave are all in use)
     if (p->K == 7 && vh::wave_code_supported(p->code) && p->nframes <= (p->code == VHIP_KA9Q27 ? WAVE_MAX_FRAMES_MOD : WAVE_MAX_FRAMES_SAT))
+        return VHIP_VARIANT_WAVE;
+    // K=9: four waves per frame (acs_wave9_kernel)
+    if (p->K == 9 && vh::wave_code_supported(p->code) && p->nframes <= (p->code == VHIP_KA9Q29 ? WAVE9_MAX_FRAMES_MOD : WAVE9_MAX_FRAMES_SAT))
         return VHIP_VARIANT_WAVE;
     if (p->K <= 9 && vh::regs_poly_supported(p->code, p->poly)) {
         // K=9 r=1/2 with few frames: one workgroup per frame (256 lanes = 256 states) finishes a 2054-step frame in
@@ -853,7 +857,7 @@ int vhip_set_variant(vhip_decoder *p, int variant) {
     variant &= 0xff;
     if (variant == VHIP_VARIANT_AUTO) variant = auto_variant(p);
     if (variant == VHIP_VARIANT_WAVE) {
-        if (!vh::wave_code_supported(p->code)) return fail("set_variant: the one-wave-per-frame kernel exists for the K=7 codes only");
+        if (!vh::wave_code_supported(p->code)) return fail("set_variant: the wave-per-frame kernels exist for the K=7 and K=9 codes only");
         p->jit = false;
         apply_variant(p, variant, 0);
         return 0;
@@ -1258,16 +1262,18 @@ int vhip_read_decision_rows(vhip_decoder *p, int frame, int row0, int nrows, uns
         return 0;
     }
     if (p->variant == VHIP_VARIANT_WAVE) {
-        // position-ordered 64-bit rows of acs_wave.hip -> natural bitmap: new state n of row r sits at position rotr^((r+1) mod 6)(n)
+        // position-ordered ballots of acs_wave.hip (N/64 64-bit words per row: word = position >> 6) -> natural bitmap: new state n of
+        // row r sits at position rotr^((r+1) mod (K-1))(n)
         const int NB = p->K - 1;
-        std::vector<unsigned long long> raw((size_t)nrows);
+        const size_t words = p->N / 64;
+        std::vector<unsigned long long> raw((size_t)nrows * words);
         HIP_TRY(hipMemcpy(raw.data(), p->d_dec + ((size_t)frame * p->cap_rows + row0) * p->row_bytes, raw.size() * 8, hipMemcpyDeviceToHost));
         memset(out, 0, (size_t)nrows * p->row_bytes);
         for (int i = 0; i < nrows; i++) {
             const int rot = (row0 + i + 1) % NB;
             for (unsigned n = 0; n < p->N; n++) {
                 const unsigned pos = rot == 0 ? n : (((n >> rot) | (n << (NB - rot))) & (p->N - 1));
-                if ((raw[(size_t)i] >> pos) & 1ull) out[(size_t)i * p->row_bytes + (n >> 3)] |= (unsigned char)(1u << (n & 7));
+                if ((raw[(size_t)i * words + (pos >> 6)] >> (pos & 63u)) & 1ull) out[(size_t)i * p->row_bytes + (n >> 3)] |= (unsigned char)(1u << (n & 7));
             }
         }
         return 0;

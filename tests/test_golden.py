@@ -71,7 +71,7 @@ def test_hip_reproduces_golden(code):
     if int(g["K"]) == 24:
         variants = [3, 4, 5]  # 5 = HBM_TILED, what AUTO picks for the harness polynomials
     if int(g["K"]) <= 9:
-        variants = [1] + [2 | ((lb + 1) << 8) for lb in (0, 1, 2)] + ([6] if int(g["K"]) == 7 else [])  # 6 = one wave per frame
+        variants = [1] + [2 | ((lb + 1) << 8) for lb in (0, 1, 2)] + [6]  # 6 = wave(s) per frame (acs_wave.hip)
     for variant in variants:
         for name in g["case_names"]:
             d = HipViterbi(HIP_NAMES[code], steps, nframes=1, variant=variant)

@@ -27,7 +27,7 @@ def variants_for(code):
         return [VARIANT_LDS, VARIANT_REGS]
     if code in (C.KA9Q27, C.SPIRAL47, C.SPIRAL27):
         return [VARIANT_LDS, regs(0), regs(1), regs(2), VARIANT_WAVE]
-    return [VARIANT_LDS, regs(0), regs(1), regs(2)]
+    return [VARIANT_LDS, regs(0), regs(1), regs(2), VARIANT_WAVE]
 
 
 def oracle_decode(code, syms, steps, nbits, endstate=0, start=0, splits=None):
@@ -548,7 +548,7 @@ def test_arbitrary_polynomials(code):
         for route in ("default", "fast", "generic"):
             want = {"default": VARIANT_AUTO, "fast": fast, "generic": generic}[route]
             dec = HipViterbi(spec.name, steps, nframes=nframes, poly=poly, variant=want)
-            if route == "default" and spec.K == 7:
+            if route == "default" and spec.K <= 9:
                 # few K=7 frames: the one-wave-per-frame kernel, which takes any polynomials as it is
                 assert not dec.runtime_specialised and dec.variant == VARIANT_WAVE
             elif route != "generic":
@@ -568,7 +568,7 @@ def test_arbitrary_polynomials(code):
     os.environ["VHIP_JIT"] = "0"
     try:
         dec = HipViterbi(spec.name, steps, nframes=1, poly=poly)
-        assert not dec.runtime_specialised and dec.variant == (VARIANT_WAVE if spec.K == 7 else generic)
+        assert not dec.runtime_specialised and dec.variant == (VARIANT_WAVE if spec.K <= 9 else generic)
         dec.close()
         with pytest.raises(VhipError):
             HipViterbi(spec.name, steps, nframes=1, poly=poly, variant=fast)
@@ -588,7 +588,7 @@ def test_jit_cache_must_be_private(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prog = ("import sys; sys.path.insert(0, %r)\n"
             "from ka9q_viterbi_comparison_amd import HipViterbi\n"
-            "d = HipViterbi('49', 100, nframes=3, poly=(0x1EF, 0x19B, 0x127, 0x1F5))\n"
+            "d = HipViterbi('49', 100, nframes=3000, poly=(0x1EF, 0x19B, 0x127, 0x1F5))\n"
             "print('SPECIALISED' if d.runtime_specialised else 'GENERIC', d.variant & 0xff)\n"
             "d.close()\n") % root
 
@@ -783,7 +783,7 @@ def test_segment_parallel_chainback(name, variant, nframes, B):
     dec.close()
 
 
-@pytest.mark.parametrize("name", ["27", "47", "spiral27"])
+@pytest.mark.parametrize("name", ["27", "47", "spiral27", "29", "49", "spiral29"])
 def test_wave_variant_long_frames_and_segmented_chainback(name):
     """The one-wave-per-frame kernels (acs_wave.hip) on frames long enough for every path: whole 48-step blocks through the LDS
     branch-metric table over several table chunks, the steps in front of and behind them (incremental updates that start

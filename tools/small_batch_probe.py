@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Update + chainback time of small batches: LDS kernel (one workgroup per frame), register kernels (frames across lanes) and,
-for K=7, the one-wave-per-frame kernel (acs_wave.hip): where should the automatic variant switch?
+"""Update + chainback time of small batches: LDS kernel (one workgroup per frame), register kernels (frames across lanes) and the
+wave-per-frame kernels (acs_wave.hip): where should the automatic variant switch?
 python tools/small_batch_probe.py"""
 import os
 import sys
@@ -21,7 +21,7 @@ for name in ("27", "47", "29", "49"):
         d_out = torch.zeros(nframes * B, dtype=torch.uint8, device="cuda")
         gen_frames_dev(spec, 1, 0, nframes, B, C.HARD_AMP_Q16, 0, d_payload, d_syms, stream)
         row = []
-        for variant in (1, 2) + ((6,) if spec.K == 7 else ()):
+        for variant in (1, 2, 6):
             dec = HipViterbi(name, steps, nframes=nframes, variant=variant, stream=stream)
             dec.enable_timing(True)
             for _ in range(3):
