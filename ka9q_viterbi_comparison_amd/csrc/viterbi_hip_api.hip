@@ -126,7 +126,10 @@ constexpr int K24_WORKERS_MIN_PLAIN = 3;
 // the register kernel, 4096 frames 0.60 + 0.12 against 0.37 + 0.19.  spiral47, whose every step also forms the wave minimum
 // (spiral47.cpp:313-331): 1024 frames 0.43 + 0.06 against 0.54 + 0.17, 2048 frames 0.85 + 0.08 against 0.55 + 0.19)
 constexpr int WAVE_MAX_FRAMES_MOD = 2048, WAVE_MAX_FRAMES_SAT = 1024;
-constexpr int WAVE9_MAX_FRAMES_MOD = 256, WAVE9_MAX_FRAMES_SAT = 256;  // K=9 (to be replaced by the measured crossover)
+// K=9, four waves per frame (same probe): ka9q29 4096 frames 0.63 + 0.24 against 1.11 + 0.32 for the register kernel, 8192 frames
+// 1.17 + 0.52 against 1.12 + 0.32; spiral49 (a barrier per step for the minimum over four waves) 2048 frames 1.28 + 0.12 against
+// 1.37 + 0.31, 4096 frames 2.46 + 0.24 against 1.38 + 0.32.  The one-workgroup-per-frame kernel (acs_lds) is slower than both everywhere.
+constexpr int WAVE9_MAX_FRAMES_MOD = 4096, WAVE9_MAX_FRAMES_SAT = 2048;
 
 // vhip_status(): -1 after a failed init / update / chainback on the handle, 0 after a successful one.  The reference ABI
 // returns void from update and a path metric (any int) from chainback_viterbi615, so the return value alone cannot
@@ -298,12 +301,6 @@ int auto_variant(const vhip_decoder *p) {
     if (p->K == 9 && vh::wave_code_supported(p->code) && p->nframes <= (p->code == VHIP_KA9Q29 ? WAVE9_MAX_FRAMES_MOD : WAVE9_MAX_FRAMES_SAT))
         return VHIP_VARIANT_WAVE;
     if (p->K <= 9 && vh::regs_poly_supported(p->code, p->poly)) {
-        // K=9 r=1/2 with few frames: one workgroup per frame (256 lanes = 256 states) finishes a 2054-step frame in
-        // 0.33 ms, the register kernel (4 lanes per frame, one wave for 16 frames) in 1.09 ms, and the two meet near
-        // 3000 frames (tools/small_batch_probe.py); for the other K <= 9 codes the register kernels win or tie everywhere
-        if (p->K == 9 && p->R == 2 && p->nframes <= 2048) return VHIP_VARIANT_LDS;
-        // r=1/4 (spiral49, whose every step also forms the workgroup minimum): 0.91-1.07 ms against 1.35-1.37 ms up to 1024 frames
-        if (p->K == 9 && p->R == 4 && p->nframes <= 1024) return VHIP_VARIANT_LDS;
         return VHIP_VARIANT_REGS;
     }
     if ((p->code == VHIP_KA9Q615 || p->code == VHIP_SPIRAL615) && vh::k15_poly_supported(p->poly)) return VHIP_VARIANT_REGS;
