@@ -84,7 +84,10 @@ struct vhip_decoder {
     int regs_lb = 0;           // REGS variant: log2(lanes per frame)
     vh::RegsLayout lay{};      // REGS variant: decision layout
     int frames_padded = 0;     // frames rounded up to a whole wave (both decision layouts fit the same buffer)
-    static constexpr int K24_WORKERS = 3;            // K=24 with several frames: this many decodes in flight
+#ifndef VH_K24_WORKERS
+#define VH_K24_WORKERS 3  // tools/k24_inflight.sh builds experiment libraries with other values (at most 7: four flag words per stream)
+#endif
+    static constexpr int K24_WORKERS = VH_K24_WORKERS;  // K=24 with several frames: this many decodes in flight
     hipStream_t aux_stream[K24_WORKERS] = {};
     unsigned long long *h_report = nullptr;          // K=24: pinned progress words (kernels.h K24Report), one per stream
     unsigned long long *h_report_dev = nullptr;      //        the same words as the device addresses them

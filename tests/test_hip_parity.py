@@ -689,14 +689,16 @@ def test_chainback_output_windows(code, variant):
     dec.close()
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(72))
 def test_chainback_fuzz(seed):
-    """Randomised geometry for the register-layout kernels (K=7 / K=9, 1, 2 or 4 lanes per frame): payload length, frames,
-    how much of the frame has been fed when chainback is called (rows never written read as zero), bit count, end state."""
+    """Randomised geometry for every K=7 / K=9 decision layout and its chainback kernels -- the register layouts (1, 2 or 4 lanes
+    per frame), the wave-per-frame layout (lanes sharing one frame's walk in verified segments) and natural rows (the same, over
+    whole rows): payload length, frames, how much of the frame has been fed when chainback is called (rows never written read
+    as zero), bit count, end state."""
     rng = np.random.default_rng(9000 + seed)
     code = [C.KA9Q27, C.SPIRAL47, C.SPIRAL27, C.KA9Q29, C.SPIRAL49, C.SPIRAL29][seed % 6]
     spec = spec_of(code)
-    variant = regs(int(rng.integers(0, 3)))
+    variant = [regs(0), regs(1), regs(2), VARIANT_WAVE, VARIANT_LDS][seed // 6 % 5] if seed >= 48 else regs(int(rng.integers(0, 3)))
     B = int(rng.integers(1, 330))
     steps = B * 8 + spec.K - 1
     nframes = int(rng.integers(1, 140))

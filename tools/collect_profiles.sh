@@ -65,6 +65,7 @@ cp $O/pmc_lds_spiral615/c_counter_collection.csv $P/${TAG}_viterbispiral615_pmc_
 for c in 27 615 224; do for k in fetch write; do cp $O/pmc_${k}_$c/c_counter_collection.csv $P/${TAG}_viterbi${c}_pmc_${k}_counter_collection.csv; done; done
 fi
 if [ "$PART" = all ] || [ "$PART" = sweep ]; then
+cd $R
 # 3. sweep, shard-size lines, harness
 python3 tools/sweep.py --out $P/${TAG}_sweep --steps 20 --cpu > $O/sweep.log 2>&1
 echo "sweep done"
