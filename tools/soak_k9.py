@@ -1,6 +1,8 @@
-"""Soak test of the K <= 9 register kernels and their chainbacks: random codes, frame counts, lengths, start / end states, ragged
-bit counts and (ka9q) update-call boundaries, default kernel selection; decision rows, metrics and decoded bytes of sampled
-frames compared with the CPU oracle.  python tools/soak_k9.py [seconds]"""
+"""Soak test of the K <= 9 kernels and their chainbacks under the handle's own kernel selection -- the wave-per-frame kernels
+(acs_wave.hip) for the small batches, the register kernels (acs_regs.hip) for the large ones: random codes, frame counts,
+lengths (one in four long enough for several branch-metric table chunks), start / end states, ragged bit counts, (ka9q)
+update-call boundaries and pipelined handles; decision rows, metrics and decoded bytes of sampled frames compared with the
+CPU oracle.  python tools/soak_k9.py [seconds]"""
 import os
 import sys
 import time
@@ -22,9 +24,9 @@ while time.time() - t0 < budget:
     name = str(rng.choice(["27", "29", "47", "49", "spiral27", "spiral29"]))
     spec = C.CODES[name]
     ka9q = name in ("27", "29")
-    B = int(rng.integers(2, 80))
+    B = int(rng.integers(2, 80)) if rng.random() < 0.75 else int(rng.integers(150, 500))
     steps = B * 8 + spec.K - 1
-    nframes = int(rng.choice([1, 3, 64, 65, 130, 700, 3000, 5000]))
+    nframes = int(rng.choice([1, 3, 64, 65, 130, 700, 3000, 5000])) if B < 150 else int(rng.choice([1, 2, 5, 70]))
     ebn0 = float(rng.choice([spec.ebn0_db, 0.0, -5.0]))
     _, syms = frames(spec.code, int(rng.integers(1, 1 << 30)), nframes, B, ebn0)
     N = 1 << (spec.K - 1)
@@ -51,7 +53,7 @@ while time.time() - t0 < budget:
         ok = all(oks)
         o.close()
         if not ok:
-            print("MISMATCH (bytes, metrics, rows ok?)", oks, name, nframes, B, start, bounds, nbits, end, depth, f, "round", rounds, flush=True)
+            print("MISMATCH (bytes, metrics, rows ok?)", oks, name, nframes, B, start, bounds, nbits, end, depth, f, "variant", dec.variant, "round", rounds, flush=True)
             sys.exit(1)
         checked += 1
     dec.close()
