@@ -382,6 +382,159 @@ __global__ __launch_bounds__(256) void acs_wave9_kernel(Args a) {
     a.metrics[(size_t)f * k9::N + rotl8(tid, (a.row0 + a.nsteps) % k9::NB)] = (int16_t)(M >> 24);
 }
 
+// ---------------------------------------------------------------------------------------------------- K = 9, spiral: one wave, four states per lane
+// The spiral decoders subtract the minimum over ALL states after every step (spiral49.cpp:790): with four waves per frame that is a
+// barrier round trip per step, more than half of the step.  Here one wave holds all 256 metrics, register r of lane l = position
+// r * 64 + l -- the same position <-> (word, bit) map as acs_wave9_kernel, so the decision layout and the chainback are shared --:
+// phases 0 and 1 pair register-index bits (registers r and r + 2, r and r + 1: no cross-lane traffic at all), phases 2..7 the lane
+// bits (the K=7 partner fetch, four times), the minimum is three v_min_u32 in the lane and one wave reduction, no barrier.
+// Waves 1..3 fill the branch-metric table ahead, as in the K=7 kernel.
+template <class C>
+__global__ __launch_bounds__(THREADS) void acs_wave9s_kernel(Args a) {
+    using namespace k9;
+    constexpr int R = C::R, NC = 1 << R;
+    constexpr int STEP_BYTES = NC * 8;
+    constexpr int CH = (TBL_BYTES / STEP_BYTES / BLK) * BLK;
+    static_assert(BLK % k9::NB == 0 && CH >= BLK, "a block is whole periods");
+    __shared__ __attribute__((aligned(16))) unsigned char tbl[2][TBL_BYTES];
+
+    const int f = blockIdx.x;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned char *syms = a.syms + (size_t)f * a.sym_stride;
+    unsigned long long *rows = a.dec + ((size_t)f * a.cap_rows + a.row0) * 4;
+    const int phi0 = a.row0 % k9::NB;
+    const int pre = min(a.nsteps, (k9::NB - phi0) % k9::NB);
+    const int nmain = ((a.nsteps - pre) / BLK) * BLK;
+    const int nchunks = (nmain + CH - 1) / CH;
+
+    auto fill = [&](int buf, int c) {
+        const int s0 = pre + c * CH, cnt = min(CH, nmain - c * CH);
+        for (int i = (int)tid - 64; i < cnt; i += THREADS - 64) {
+            int s[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) s[r] = syms[(size_t)(s0 + i) * R + r];
+            uint2 *e = reinterpret_cast<uint2 *>(&tbl[buf][i * STEP_BYTES]);
+#pragma unroll
+            for (int cl = 0; cl < NC; cl++) {
+                const int t = C::bm(s, (unsigned)cl);
+                e[cl] = make_uint2((unsigned)t << 24, (unsigned)C::bm_tc(t) << 24);
+            }
+        }
+    };
+
+    unsigned M[4] = {0, 0, 0, 0};
+    unsigned cls[k9::NB][4], aoff[k9::NB][4];
+    bool up[k9::NB];  // phases 2..7: this lane holds the upper predecessor (the same for its four registers)
+    if (wave == 0) {
+#pragma unroll
+        for (int p = 0; p < k9::NB; p++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const unsigned st = rotl8((unsigned)r * 64u + lane, p);
+                cls[p][r] = bt_class<R>(st & (k9::H - 1u), a.poly);
+                aoff[p][r] = cls[p][r] * 8u;
+            }
+            up[p] = p >= 2 ? ((lane >> (k9::NB - 1 - p)) & 1u) != 0 : false;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) M[r] = to_lane_metric<C>(a.metrics[(size_t)f * k9::N + rotl8((unsigned)r * 64u + lane, phi0)]);
+    }
+    // one trellis step at phase PHI: e[r] = {t, t'} of register r's butterfly; d[r] = decision of the new state now in register r
+    auto step9 = [&](auto P, const uint2 (&e)[4], bool (&d)[4]) {
+        constexpr int PHI = decltype(P)::value;
+        if constexpr (PHI >= 2) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) d[r] = acs<C>(M[r], partner<k9::NB - 1 - PHI>(M[r], lane), e[r].x, e[r].y, up[PHI]);
+        } else {
+            constexpr int S = PHI == 0 ? 2 : 1;  // partner register: r ^ 2 (position bit 7) or r ^ 1 (bit 6)
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int lo = PHI == 0 ? k : 2 * k, hi = lo + S;
+                const unsigned old_lo = M[lo], old_hi = M[hi];
+                d[lo] = acs<C>(M[lo], old_hi, e[lo].x, e[lo].y, false);
+                d[hi] = acs<C>(M[hi], old_lo, e[hi].x, e[hi].y, true);
+            }
+        }
+        if constexpr (C::renorm) {  // state 0 is position 0: register 0 of lane 0
+            const unsigned m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)M[0]);
+            if (m0 > (((unsigned)C::renorm_thr << 24) | 0x00ffffffu)) {
+                const unsigned mn = wave_min_u32(min(min(M[0], M[1]), min(M[2], M[3]))) & 0xff000000u;
+#pragma unroll
+                for (int r = 0; r < 4; r++) M[r] -= mn;
+            }
+        }
+    };
+    auto slow_step = [&](int i) {
+        int s[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) s[r] = syms[(size_t)i * R + r];
+        const int phi = (a.row0 + i) % k9::NB;
+        bool d[4] = {false, false, false, false};
+        sfor<k9::NB>([&](auto P) {
+            constexpr int PHI = decltype(P)::value;
+            if (phi == PHI) {  // uniform
+                uint2 e[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int t = C::bm(s, cls[PHI][r]);
+                    e[r] = make_uint2((unsigned)t << 24, (unsigned)C::bm_tc(t) << 24);
+                }
+                step9(P, e, d);
+            }
+        });
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const unsigned long long row = __builtin_amdgcn_ballot_w64(d[r]);
+            if (lane == 0) rows[(size_t)i * 4 + r] = row;
+        }
+    };
+
+    if (wave == 0) {
+        for (int i = 0; i < pre; i++) slow_step(i);
+    } else if (nchunks > 0) {
+        fill(0, 0);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; c++) {
+        if (wave == 0) {
+            const int cnt = min(CH, nmain - c * CH);
+            const unsigned char *tb = tbl[c & 1];
+            for (int b0 = 0; b0 < cnt; b0 += BLK) {
+                unsigned acc[4][2] = {};
+                const unsigned char *blk = tb + b0 * STEP_BYTES;
+                sfor<BLK>([&](auto J) {
+                    constexpr int j = decltype(J)::value, PHI = j % k9::NB;
+                    uint2 e[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) e[r] = *reinterpret_cast<const uint2 *>(blk + aoff[PHI][r] + j * STEP_BYTES);
+                    bool d[4];
+                    step9(std::integral_constant<int, PHI>{}, e, d);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const unsigned long long row = __builtin_amdgcn_ballot_w64(d[r]);
+                        acc[r][0] = writelane<j>(acc[r][0], (unsigned)row);
+                        acc[r][1] = writelane<j>(acc[r][1], (unsigned)(row >> 32));
+                    }
+                });
+                if (lane < (unsigned)BLK) {  // lane j holds the four words of row j: 32 contiguous bytes
+                    uint4 *dst = reinterpret_cast<uint4 *>(rows + (size_t)(pre + c * CH + b0 + (int)lane) * 4);
+                    dst[0] = make_uint4(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+                    dst[1] = make_uint4(acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
+                }
+            }
+        } else if (c + 1 < nchunks) {
+            fill((c + 1) & 1, c + 1);
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        for (int i = pre + nmain; i < a.nsteps; i++) slow_step(i);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            a.metrics[(size_t)f * k9::N + rotl8((unsigned)r * 64u + lane, (a.row0 + a.nsteps) % k9::NB)] = (int16_t)(M[r] >> 24);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- chainback
 // chainback_viterbi27_sse2 (viterbi27_sse2.cpp:78-105) / chainback_spiral47 (spiral47.cpp:84-121) over position-ordered rows:
 // one wave per frame.  The walk runs in position space (chainback_k7_lds_kernel in acs_regs.hip explains it): p =
@@ -532,8 +685,9 @@ hipError_t launch_acs_wave(int code, const AcsLdsArgs &l, hipStream_t stream) {
     case VHIP_SPIRAL47: hipLaunchKernelGGL(wave7::acs_wave_kernel<Code47>, dim3(a.nframes), dim3(wave7::THREADS), 0, stream, a); break;
     case VHIP_SPIRAL27: hipLaunchKernelGGL(wave7::acs_wave_kernel<CodeS27>, dim3(a.nframes), dim3(wave7::THREADS), 0, stream, a); break;
     case VHIP_KA9Q29: hipLaunchKernelGGL(wave7::acs_wave9_kernel<Code29>, dim3(a.nframes), dim3(256), 0, stream, a); break;
-    case VHIP_SPIRAL49: hipLaunchKernelGGL(wave7::acs_wave9_kernel<Code49>, dim3(a.nframes), dim3(256), 0, stream, a); break;
-    case VHIP_SPIRAL29: hipLaunchKernelGGL(wave7::acs_wave9_kernel<CodeS29>, dim3(a.nframes), dim3(256), 0, stream, a); break;
+    // spiral K=9: one wave with four states per lane (no barrier behind the per-step minimum)
+    case VHIP_SPIRAL49: hipLaunchKernelGGL(wave7::acs_wave9s_kernel<Code49>, dim3(a.nframes), dim3(wave7::THREADS), 0, stream, a); break;
+    case VHIP_SPIRAL29: hipLaunchKernelGGL(wave7::acs_wave9s_kernel<CodeS29>, dim3(a.nframes), dim3(wave7::THREADS), 0, stream, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
