@@ -1,11 +1,11 @@
-// acs_wave.hip -- the LATENCY geometry for K=7: one wavefront = one frame, one trellis state per lane.
+// acs_wave.hip -- the LATENCY geometry for K=7 and K=9: whole wavefronts per frame, one trellis state per lane.
 //
 // The reference's own methodology decodes ONE frame per handle, one blocking call at a time (src/main.cpp:257-280), and
 // update_viterbi27_blk_sse2 / update_spiral47 (ka9q_libfec_port/viterbi27_sse2.cpp:119-175, spiral/spiral47.cpp:131-538) walk its
 // trellis steps one after the other.  A frame is a single chain of dependent steps, so what bounds it on a GPU is the number of
 // instructions ONE wave has to issue per step (a lone wave issues one instruction per ~4-5 cycles whatever its kind): the
 // throughput kernels of acs_regs.hip spend ~70 instructions per step on a frame held by four lanes (0.18 us per step).  Here
-// the 64 lanes of a wave hold the 64 path metrics and a step is ~12 instructions:
+// the 64 lanes of a wave hold 64 path metrics and a K=7 step is ~14 instructions:
 //   * the rotating in-place trellis of acs_regs.hip: position p (= lane p) holds state rotl^phi(p) before the step of phase
 //     phi = row mod 6, the butterfly partner is lane p ^ (1 << (5 - phi)) -- one DPP operand (quad_perm), two bank-masked DPP
 //     row shifts, or one v_permlane16/32_swap (gfx950) -- and no metric ever moves;
@@ -15,9 +15,13 @@
 //   * metrics sit in the top byte of a dword: a 32-bit add wraps like _mm_add_epi8 (ka9q) or, as (m << 24) | 0xffffff with the
 //     clamp bit, saturates like _mm_adds_epu8 (spiral), and the sign of a 32-bit difference is that of the 8-bit one;
 //   * the 64 decisions of a step are one ballot; 48 of them are parked in two VGPRs (v_writelane) and leave as one store.
-// Decisions: [frame][row] 64-bit words in POSITION order (bit p of row r = decision of the new state rotl^((r+1) mod 6)(p)):
-// exactly N/8 bytes per frame-row like every other layout.  Any polynomial set works (classes are computed per lane at run
-// time).  Arithmetic per family exactly as acs_lds.hip.  chainback: chainback_wave_kernel below.
+// Three kernels: acs_wave_kernel (K=7, one wave per frame), acs_wave9_kernel (ka9q K=9: four waves per frame, the two wave-bit
+// phases through an LDS exchange), acs_wave9s_kernel (spiral K=9: one wave, four states per lane, so that the minimum the spiral
+// decoders subtract after every step needs no barrier).
+// Decisions: [frame][row][N/64] 64-bit words in POSITION order (bit p & 63 of word p >> 6 of row r = decision of the new state
+// rotl^((r+1) mod (K-1))(p)): exactly N/8 bytes per frame-row like every other layout.  Any polynomial set works (classes are
+// computed per lane at run time).  Arithmetic per family exactly as acs_lds.hip.  chainback:
+// chainback_wave_kernel below (the 64 lanes share one frame's walk).
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
