@@ -76,3 +76,18 @@ def test_harness_rejects_zero_time_and_zero_samples():
     for flags in (["-t", "0"], ["-t", "-1"], ["-n", "0"]):
         r = subprocess.run([BIN] + flags, capture_output=True, text=True, timeout=60)
         assert r.returncode == 1, (flags, r.returncode, r.stderr)
+
+
+@pytest.mark.gpu
+def test_harness_gpus_argument(tmp_path):
+    """--gpus N shards the frames over N devices (one host thread and one stream per device, hipSetDevice per shard).  One GPU is
+    what the test box has: --gpus 1 runs the sharded path with a single shard (same JSON, `gpus` 1, frames_per_gpu = frames) and
+    asking for more devices than are visible is refused before anything is decoded."""
+    out = tmp_path / "g.json"
+    r = subprocess.run([BIN, "-t", "0.05", "-n", "2", "-o", str(out), "--gpus", "1", "--frames", "512", "--payload-bytes", "32", "--hard",
+                        "--codes", "27,615"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for e in json.load(open(out)):
+        assert e["gpus"] == 1 and e["frames"] == 512 and e["frames_per_gpu"] == 512 and e["total_bit_errors"] == 0
+    r = subprocess.run([BIN, "-t", "0.05", "-n", "2", "-o", str(out), "--gpus", "64", "--codes", "27"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "device(s) visible" in r.stderr
