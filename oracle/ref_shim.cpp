@@ -213,4 +213,18 @@ long ref_bench_loop(int code, void *p, const unsigned char *syms, int nsample, l
     return n;
 }
 
+// Decodes `nframes` frames one after the other with ONE decoder object (reset + update + chainback per frame, the harness's call
+// sequence) and keeps every frame's bytes: the whole-batch parity tests compare a full GPU batch with this.
+void ref_decode_batch(int code, void *p, const unsigned char *syms, long nframes, long frame_stride, int steps, unsigned nbits,
+                      unsigned char *out, long out_stride) {
+    std::vector<unsigned char> tmp((size_t)frame_stride);
+    for (long f = 0; f < nframes; f++) {
+        memcpy(tmp.data(), syms + (size_t)f * (size_t)frame_stride, (size_t)frame_stride);  // the reference takes unsigned char*, not const
+        ref_init(code, p, 0);
+        ref_update(code, p, tmp.data(), steps);
+        memset(out + (size_t)f * (size_t)out_stride, 0, (size_t)out_stride);
+        ref_chainback(code, p, out + (size_t)f * (size_t)out_stride, nbits, 0);
+    }
+}
+
 }  // extern "C"

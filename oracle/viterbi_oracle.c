@@ -398,3 +398,16 @@ long vo_bench_loop(vo_decoder *p, const unsigned char *syms, int nsample, long f
     *elapsed = el;
     return n;
 }
+
+/* Decodes nframes frames one after the other with one decoder (reset + update + chainback per frame) and keeps every frame's
+ * bytes: what the whole-batch parity tests compare a full GPU batch with where the compiled reference is absent. */
+void vo_decode_batch(vo_decoder *p, const unsigned char *syms, long nframes, long frame_stride, int steps, unsigned nbits,
+                     unsigned char *out, long out_stride) {
+    for (long f = 0; f < nframes; f++) {
+        vo_init(p, 0);
+        vo_update_blk(p, syms + (size_t)f * (size_t)frame_stride, steps);
+        memset(out + (size_t)f * (size_t)out_stride, 0, (size_t)out_stride);
+        vo_chainback(p, out + (size_t)f * (size_t)out_stride, nbits, 0);
+    }
+}
+

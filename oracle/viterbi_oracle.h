@@ -75,6 +75,10 @@ size_t vo_encode(int K, int R, const int *poly, const unsigned char *payload, si
 long vo_bench_loop(vo_decoder *p, const unsigned char *syms, int nsample, long frame_stride, int steps, unsigned nbits,
                    double seconds, double *elapsed);
 
+/* whole-batch parity tests: nframes frames decoded one after the other (reset + update + chainback each), all bytes kept */
+void vo_decode_batch(vo_decoder *p, const unsigned char *syms, long nframes, long frame_stride, int steps, unsigned nbits,
+                     unsigned char *out, long out_stride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,8 @@ def oracle():
         lib.vo_code_R.argtypes = [C.c_int]
         lib.vo_encode.restype = C.c_size_t
         lib.vo_encode.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.vo_decode_batch.restype = None
+        lib.vo_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_uint, C.c_void_p, C.c_long]
         lib.vo_bench_loop.restype = C.c_long
         lib.vo_bench_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_uint, C.c_double, C.POINTER(C.c_double)]
         _oracle = lib
@@ -69,6 +71,8 @@ def ref(w32=False):
         lib.ref_metrics.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         lib.ref_metrics.restype = None
         lib.ref_sizeof_long.restype = C.c_int
+        lib.ref_decode_batch.restype = None
+        lib.ref_decode_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_uint, C.c_void_p, C.c_long]
         lib.ref_bench_loop.restype = C.c_long
         lib.ref_bench_loop.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_uint, C.c_double, C.POINTER(C.c_double)]
         _refs[path] = lib
@@ -191,3 +195,37 @@ def encode(K, R, poly, payload):
     n = oracle().vo_encode(K, R, _poly(poly), p.ctypes.data_as(C.c_void_p), p.size, out.ctypes.data_as(C.c_void_p))
     assert n == out.size
     return out
+
+
+def decode_batch_cpu(code, poly, syms, steps, nbits, threads=8):
+    """Every frame of `syms` ([nframes, steps*R] uint8) decoded on the CPU -- by the compiled reference where oracle/_ref is
+    present (kind "reference"), else by the plain-C restatement -- with reset + update + chainback per frame, as the harness calls
+    them.  Frames are split over `threads` decoder objects (ctypes releases the GIL).  Returns (bytes [nframes, ceil(nbits/8)], kind)."""
+    import concurrent.futures as cf
+
+    syms = np.ascontiguousarray(syms, dtype=np.uint8)
+    nframes, stride = syms.shape
+    nb = (nbits + 7) // 8
+    out = np.zeros((nframes, nb), dtype=np.uint8)
+    use_ref = have_ref()
+    w32 = code == 2  # ka9q615: the 32-bit-word chainback (SURVEY.md §0.3)
+    decs = [(RefDecoder(code, poly, steps, w32=w32) if use_ref else OracleDecoder(code, poly, steps)) for _ in range(threads)]  # serially: table init is not thread-safe
+    bounds = np.linspace(0, nframes, threads + 1).astype(int)
+
+    def work(k):
+        lo, hi = int(bounds[k]), int(bounds[k + 1])
+        if hi <= lo:
+            return
+        d = decs[k]
+        sp = C.c_void_p(syms.ctypes.data + lo * stride)
+        op = C.c_void_p(out.ctypes.data + lo * nb)
+        if use_ref:
+            d.lib.ref_decode_batch(code, d.h, sp, hi - lo, stride, steps, nbits, op, nb)
+        else:
+            d.lib.vo_decode_batch(d.h, sp, hi - lo, stride, steps, nbits, op, nb)
+
+    with cf.ThreadPoolExecutor(threads) as ex:
+        list(ex.map(work, range(threads)))
+    for d in decs:
+        d.close()
+    return out, ("reference" if use_ref else "port")

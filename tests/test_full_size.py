@@ -81,6 +81,33 @@ def test_config3_k15_4096_frames():
         assert np.array_equal(out[f], oracle_frame(spec, s, steps, bits)), f
 
 
+@pytest.mark.parametrize("name,frames", [("27", 65536), ("47", 65536), ("29", 32768), ("49", 32768), ("615", 4096), ("spiral615", 512)])
+def test_whole_batch_equals_the_reference(name, frames):
+    """configs[1] / configs[2] and the sweep codes at their bench sizes, EVERY frame: the batch the bench decodes (AWGN symbols
+    generated on the device, the handle's own kernel selection, i.e. the production kernels) against the reference's own
+    decoders (oracle/_ref -- the reference's translation units compiled by oracle/Makefile; the plain-C restatement where that
+    library is absent) run over all frames on the host cores with the harness's call sequence.  All decoded bytes must be equal:
+    65536 x 256 bytes for configs[1], 4096 x 256 for configs[2] (K=15: the 32-bit-word chainback)."""
+    import os
+
+    import oracle_lib as ol
+
+    bits = 2048
+    spec, d_payload, d_syms, d_out = decode_batch(name, frames, bits, hard=False)
+    steps = bits + spec.K - 1
+    syms = d_syms.cpu().numpy().reshape(frames, steps * spec.R)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    want, kind = ol.decode_batch_cpu(spec.code, spec.poly, syms, steps, bits, threads=max(1, min(16, cores)))
+    got = d_out.cpu().numpy().reshape(frames, bits // 8)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} of {frames} frames differ from the {kind} decoder, first {bad[:5]}"
+    errs = count_bit_errors_dev(d_out, d_payload, frames * bits // 8)
+    assert errs < frames * bits * 2e-2  # a working decoder at the operating point (spiral615's 8-bit metrics: ~1e-2)
+
+
 @pytest.mark.parametrize("bits", [2048, 16384])
 def test_config4_k24_long_frame(bits):
     """configs[3]: K=24 single long frame.  Round trip through the correct chainback convention (nbits+K-1,

@@ -239,3 +239,24 @@ def test_adversarial_symbols(code):
         compare(o, r, (steps // 2) * 2 if code >= C.SPIRAL47 else steps, B * 8)
         o.close()
         r.close()
+
+
+@pytest.mark.parametrize("code", [C.KA9Q27, C.SPIRAL49, C.KA9Q615])
+def test_batch_helper_equals_single_frame_calls(code):
+    """oracle_lib.decode_batch_cpu (what the whole-batch GPU tests compare with: every frame decoded on the host cores, several decoder
+    objects in threads) gives the bytes of one-frame-at-a-time calls on the restatement, frame for frame."""
+    import oracle_lib as ol
+
+    spec = spec_of(code)
+    B, n = 24, 37
+    steps = B * 8 + spec.K - 1
+    steps -= 0 if spec.family.startswith("ka9q") else steps % 2
+    _, syms = frames(code, 99, n, B, spec.ebn0_db - 2.0)
+    syms = np.ascontiguousarray(syms[:, :steps * spec.R])
+    got, kind = ol.decode_batch_cpu(code, spec.poly, syms, steps, B * 8, threads=3)
+    assert kind == ("reference" if ol.have_ref() else "port")
+    for f in range(n):
+        o = OracleDecoder(code, spec.poly, steps)
+        o.update(syms[f], steps)
+        assert np.array_equal(got[f], o.chainback(B * 8)[0]), f
+        o.close()
