@@ -235,9 +235,15 @@ __global__ __launch_bounds__(THREADS) void acs_wave_kernel(Args a) {
             for (int b0 = 0; b0 < cnt; b0 += BLK) {
                 unsigned acc_lo = 0, acc_hi = 0;
                 const unsigned char *blk = tb + b0 * STEP_BYTES;
+                // the table entries of a whole period are fetched one period ahead: an LDS read issued a step ahead is not back in
+                // time for a ~90-cycle step
+                uint2 en[NB];
+#pragma unroll
+                for (int q = 0; q < NB; q++) en[q] = *reinterpret_cast<const uint2 *>(blk + aoff[q] + q * STEP_BYTES);
                 sfor<BLK>([&](auto J) {
                     constexpr int j = decltype(J)::value, PHI = j % NB;
-                    const uint2 e = *reinterpret_cast<const uint2 *>(blk + aoff[PHI] + j * STEP_BYTES);
+                    const uint2 e = en[PHI];
+                    if constexpr (j + NB < BLK) en[PHI] = *reinterpret_cast<const uint2 *>(blk + aoff[PHI] + (j + NB) * STEP_BYTES);
                     const bool d = step<C, PHI>(M, e.x, e.y, up[PHI], lane);
                     renormalise<C>(M);
                     const unsigned long long row = __builtin_amdgcn_ballot_w64(d);
