@@ -375,9 +375,13 @@ __global__ __launch_bounds__(256) void acs_wave9_kernel(Args a) {
         for (int b0 = 0; b0 < cnt; b0 += BLK) {
             unsigned acc_lo = 0, acc_hi = 0;
             const unsigned char *blk = tbl + b0 * STEP_BYTES;
+            uint2 en[k9::NB];  // table entries fetched one period ahead (see acs_wave_kernel)
+#pragma unroll
+            for (int q = 0; q < k9::NB; q++) en[q] = *reinterpret_cast<const uint2 *>(blk + aoff[q] + q * STEP_BYTES);
             sfor<BLK>([&](auto J) {
                 constexpr int j = decltype(J)::value, PHI = j % k9::NB;
-                const uint2 e = *reinterpret_cast<const uint2 *>(blk + aoff[PHI] + j * STEP_BYTES);
+                const uint2 e = en[PHI];
+                if constexpr (j + k9::NB < BLK) en[PHI] = *reinterpret_cast<const uint2 *>(blk + aoff[PHI] + (j + k9::NB) * STEP_BYTES);
                 const unsigned X = fetch(std::integral_constant<int, PHI>{});
                 const bool d = acs<C>(M, X, e.x, e.y, up[PHI]);
                 renorm();
@@ -512,11 +516,19 @@ __global__ __launch_bounds__(THREADS) void acs_wave9s_kernel(Args a) {
             for (int b0 = 0; b0 < cnt; b0 += BLK) {
                 unsigned acc[4][2] = {};
                 const unsigned char *blk = tb + b0 * STEP_BYTES;
+                uint2 en[k9::NB][4];  // table entries fetched one period ahead (see acs_wave_kernel)
+#pragma unroll
+                for (int q = 0; q < k9::NB; q++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) en[q][r] = *reinterpret_cast<const uint2 *>(blk + aoff[q][r] + q * STEP_BYTES);
                 sfor<BLK>([&](auto J) {
                     constexpr int j = decltype(J)::value, PHI = j % k9::NB;
                     uint2 e[4];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) e[r] = *reinterpret_cast<const uint2 *>(blk + aoff[PHI][r] + j * STEP_BYTES);
+                    for (int r = 0; r < 4; r++) {
+                        e[r] = en[PHI][r];
+                        if constexpr (j + k9::NB < BLK) en[PHI][r] = *reinterpret_cast<const uint2 *>(blk + aoff[PHI][r] + (j + k9::NB) * STEP_BYTES);
+                    }
                     bool d[4];
                     step9(std::integral_constant<int, PHI>{}, e, d);
 #pragma unroll

@@ -1,8 +1,9 @@
 """BASELINE.json configs[4] -- the full sweep {27, 29, 47, 49, 615, 224} x 1M frames sharded over 8 GPUs -- at its per-GPU
 size on ONE GPU (131072 frames per code; src/main.cpp:363-419 is the reference's block list).  No 8-GPU node is available
 to the builder, so what one rank does is what can be checked: every frame of a noise-free batch decodes without error,
-and frames sampled from an AWGN batch -- from both ends, from the middle and from beyond the 2^31-byte offset of the
-decision history -- equal the CPU oracle byte for byte.  K=15 goes through the double-buffered handle in HBM-sized chunks
+frames sampled from an AWGN batch -- from both ends, from the middle and from beyond the 2^31-byte offset of the
+decision history -- equal the CPU oracle byte for byte, and for the K <= 9 codes every frame of that batch equals the
+reference's own decoder (oracle/_ref) run over all 131072 frames on the host cores.  K=15 goes through the double-buffered handle in HBM-sized chunks
 exactly as bench.HipShard does (131072 frames x 4.2 MB of decisions do not fit); K=24 runs the reduced share a rank
 would get (stated below), compared with the oracle in full."""
 import argparse
@@ -73,6 +74,20 @@ def test_config5_shard_per_code(name):
     for f in sample:
         ref = oracle_bytes(spec, sy[f].cpu().numpy(), steps, BITS)
         assert np.array_equal(got[f].cpu().numpy(), ref), (name, f)
+    if spec.K <= 9:
+        # ... and for K <= 9 EVERY one of the 131072 frames against the reference's own decoder on the host cores (a few seconds;
+        # K=15 would take a quarter of an hour and stays sampled)
+        import os
+
+        import oracle_lib as ol
+
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:
+            cores = os.cpu_count() or 1
+        want, kind = ol.decode_batch_cpu(spec.code, spec.poly, sy.cpu().numpy(), steps, BITS, threads=max(1, min(16, cores)))
+        bad = np.nonzero((got.cpu().numpy() != want).any(axis=1))[0]
+        assert bad.size == 0, f"{bad.size} of {FRAMES} frames differ from the {kind} decoder, first {bad[:5]}"
     errs = count_bit_errors_dev(shard.d_out[0], shard.d_payload, FRAMES * B, shard.stream.cuda_stream)
     assert errs < FRAMES * BITS * 2e-3, errs  # a working decoder at the operating point, not garbage
     shard.close()

@@ -226,6 +226,15 @@ def test_config5_shard_size_k7_131072_frames():
     for f in (0, 65535, 65536, 130689, 130690, 130700, 131071):
         s = d_syms[f * steps * spec.R:(f + 1) * steps * spec.R].cpu().numpy()
         assert np.array_equal(out[f], oracle_frame(spec, s, steps, bits)), f
+    # every frame against the reference's own decoder (one handle, 131072 frames, history offsets beyond 2^31 included)
+    import os
+
+    import oracle_lib as ol
+
+    want, kind = ol.decode_batch_cpu(spec.code, spec.poly, d_syms.cpu().numpy().reshape(frames, steps * spec.R), steps, bits,
+                                     threads=max(1, min(16, len(os.sched_getaffinity(0)))))
+    bad = np.nonzero((out != want).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} of {frames} frames differ from the {kind} decoder, first {bad[:5]}"
     errs = count_bit_errors_dev(d_out, d_payload, frames * bits // 8)
     assert 0 < errs < frames * bits * 1e-3
 
