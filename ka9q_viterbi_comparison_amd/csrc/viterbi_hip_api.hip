@@ -130,9 +130,9 @@ constexpr int K24_WORKERS_MIN_PLAIN = 3;
 // (spiral47.cpp:313-331): 1024 frames 0.43 + 0.06 against 0.54 + 0.17, 2048 frames 0.85 + 0.08 against 0.55 + 0.19)
 constexpr int WAVE_MAX_FRAMES_MOD = 2048, WAVE_MAX_FRAMES_SAT = 1024;
 // K=9 (same probe): ka9q29, four waves per frame: 4096 frames 0.63 + 0.24 against 1.11 + 0.32 for the register kernel, 8192 frames
-// 1.17 + 0.52 against 1.12 + 0.32; spiral49, one wave with four states per lane: 1024 frames 0.79 + 0.05 against 1.37 + 0.31, 2048 frames
-// 1.56 + 0.12 against 1.37 + 0.31.  The one-workgroup-per-frame kernel (acs_lds) is slower than both everywhere.
-constexpr int WAVE9_MAX_FRAMES_MOD = 4096, WAVE9_MAX_FRAMES_SAT = 1024;
+// 1.17 + 0.52 against 1.12 + 0.32; spiral49, one wave with four states per lane: 2048 frames 1.36 + 0.12 against 1.36 + 0.31, 4096 frames
+// 2.71 + 0.25 against 1.37 + 0.32.  The one-workgroup-per-frame kernel (acs_lds) is slower than both everywhere.
+constexpr int WAVE9_MAX_FRAMES_MOD = 4096, WAVE9_MAX_FRAMES_SAT = 2048;
 
 // vhip_status(): -1 after a failed init / update / chainback on the handle, 0 after a successful one.  The reference ABI
 // returns void from update and a path metric (any int) from chainback_viterbi615, so the return value alone cannot
