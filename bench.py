@@ -112,9 +112,24 @@ def cpu_baseline(spec, payload_bits, budget_s=12.0):
     decs = [make() for _ in range(cores)]  # created serially: the reference's table init is not thread-safe
     n1, t1 = work(decs[0], budget_s * 0.4)
     single = n1 * steps * spec.R / t1 / 1e6
+    # one decoder per thread, each thread pinned to its own CPU of the allowed set (unpinned, the all-core figure of the same
+    # 16 threads swung between 2.6 and 4.2 Gsym/s from run to run as the scheduler moved them around a 256-CPU host)
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except Exception:
+        cpus = []
+
+    def pinned(k):
+        if len(cpus) >= cores:
+            try:
+                os.sched_setaffinity(0, {cpus[k]})  # pid 0 = the calling thread
+            except Exception:
+                pass
+        return work(decs[k], budget_s * 0.6)
+
     with cf.ThreadPoolExecutor(cores) as ex:
         t0 = time.perf_counter()
-        res = list(ex.map(lambda d: work(d, budget_s * 0.6), decs))
+        res = list(ex.map(pinned, range(cores)))
         wall = time.perf_counter() - t0
     nall = sum(r[0] for r in res)
     multi = nall * steps * spec.R / wall / 1e6
@@ -125,6 +140,7 @@ def cpu_baseline(spec, payload_bits, budget_s=12.0):
         "unit": "Msymbols/s",
         "cores": cores,
         "cores_available": cores_available,
+        "pinned": len(cpus) >= cores,
         "kind": "reference" if use_ref else "port",
         "build": build,
         "single_thread_value": round(single, 6),
