@@ -12,8 +12,9 @@
 //   * the branch metrics do not depend on the path metrics, so the OTHER three waves of the workgroup compute them ahead, for
 //     every class of the branch table, into an LDS table (double-buffered chunks): on the serial chain a step's {t, t'} is one
 //     ds_read_b64 at a per-lane class offset;
-//   * metrics sit in the top byte of a dword: a 32-bit add wraps like _mm_add_epi8 (ka9q) or, as (m << 24) | 0xffffff with the
-//     clamp bit, saturates like _mm_adds_epu8 (spiral), and the sign of a 32-bit difference is that of the 8-bit one;
+//   * ka9q: metrics in the top byte of a dword -- a 32-bit add wraps like _mm_add_epi8 and the sign of a 32-bit difference is that of
+//     the 8-bit one; spiral: plain integers with a lazy offset, so that "subtract the minimum" after (nearly) every step is a scalar
+//     assignment and _mm_adds_epu8's saturation a minimum with a scalar cap (struct Lazy below);
 //   * the 64 decisions of a step are one ballot; 48 of them are parked in two VGPRs (v_writelane) and leave as one store.
 // Three kernels: acs_wave_kernel (K=7, one wave per frame), acs_wave9_kernel (ka9q K=9: four waves per frame, the two wave-bit
 // phases through an LDS exchange), acs_wave9s_kernel (spiral K=9: one wave, four states per lane, so that the minimum the spiral
@@ -89,16 +90,31 @@ __device__ __forceinline__ unsigned writelane(unsigned acc, unsigned sval) {
     return (unsigned)vh_writelane_i32((int)sval, LANE, (int)acc);
 }
 
+// Metric representation.  ka9q (u8 modular): the metric in the TOP byte of a dword -- a 32-bit add wraps like _mm_add_epi8 and the
+// sign of a 32-bit difference is that of the 8-bit one.  spiral (u8 saturating, minimum subtracted after nearly every step):
+// plain integers with a LAZY offset -- the register holds true + off, the saturation of _mm_adds_epu8 at 255 becomes a minimum with
+// cap = 255 + off, and "subtract the minimum" is off = min(registers): a scalar assignment instead of a vector subtract, and the
+// wave reduction it needs leaves the serial chain of the next step's adds (only its final minimum waits for the cap).  Exact:
+// the register is true + off after every step, the fire test and the capped comparisons are the reference's shifted by off.
+template <class C>
+constexpr int metric_shift() { return C::metric == U8MOD ? 24 : 0; }
+struct Lazy {
+    unsigned off = 0, cap = 255;
+};
 template <class C>
 __device__ __forceinline__ unsigned to_lane_metric(int m) {
-    if constexpr (C::metric == U8MOD) return ((unsigned)m & 255u) << 24;
-    else return (((unsigned)m & 255u) << 24) | 0x00ffffffu;
+    return ((unsigned)m & 255u) << metric_shift<C>();
+}
+template <class C>
+__device__ __forceinline__ int from_lane_metric(unsigned M, const Lazy &lz) {
+    if constexpr (C::metric == U8MOD) return (int)(M >> 24);
+    else return (int)(M - lz.off);
 }
 
 // Add-compare-select of one lane.  M: this lane's metric, X: its butterfly partner's, tv / tcv: the butterfly's branch metrics
 // t and t' in the top byte, up: this lane holds old[j + H].  Returns the decision of the new state that now lives in this lane.
 template <class C>
-__device__ __forceinline__ bool acs(unsigned &M, unsigned X, unsigned tv, unsigned tcv, bool up) {
+__device__ __forceinline__ bool acs(unsigned &M, unsigned X, unsigned tv, unsigned tcv, bool up, const Lazy &lz) {
     if constexpr (C::metric == U8MOD) {
         // lower position: m0 = old[j] + t (self), m1 = old[j+H] + t' (partner); upper position: m2 = old[j] + t' (partner),
         // m3 = old[j+H] + t (self)                                                       viterbi27_sse2.cpp:149-152
@@ -110,17 +126,20 @@ __device__ __forceinline__ bool acs(unsigned &M, unsigned X, unsigned tv, unsign
         M = lo - (unsigned)max(diff, 0);
         return d;
     } else {
-        const unsigned cs = __builtin_elementwise_add_sat(M, tv), co = __builtin_elementwise_add_sat(X, tcv);  // adds_epu8  spiral47.cpp:220-223
-        const unsigned lo = up ? co : cs, hi = up ? cs : co;
-        const bool d = hi <= lo;            // min_epu8 + cmpeq(min, upper): tie -> upper          :224-227
-        M = min(cs, co);
+        // adds_epu8 (spiral47.cpp:220-223) = min(x + t, 255) on the true values = min(register + t, cap) here; the upper
+        // predecessor's candidate is the partner's for a lower position, this lane's own for an upper one
+        const unsigned cs = M + tv, co = X + tcv;
+        const unsigned nw = min(min(cs, co), lz.cap);   // min_epu8 of the two saturated candidates          :224-225
+        const unsigned upper = min(up ? cs : co, lz.cap);
+        const bool d = nw == upper;                     // cmpeq(min, upper): tie -> upper                   :226-227
+        M = nw;
         return d;
     }
 }
 // One trellis step of the K=7 kernel at phase PHI: the partner is lane ^ (1 << (5 - PHI)).
 template <class C, int PHI>
-__device__ __forceinline__ bool step(unsigned &M, unsigned tv, unsigned tcv, bool up, unsigned lane) {
-    return acs<C>(M, partner<NB - 1 - PHI>(M, lane), tv, tcv, up);
+__device__ __forceinline__ bool step(unsigned &M, unsigned tv, unsigned tcv, bool up, unsigned lane, const Lazy &lz) {
+    return acs<C>(M, partner<NB - 1 - PHI>(M, lane), tv, tcv, up, lz);
 }
 
 // spiral47.cpp:313-331: after every step, if new[0] > threshold, subtract the minimum over all states (saturating; nothing
@@ -138,11 +157,28 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
     return min(min(a, b), min(c, d));
 }
+// spiral47.cpp:313-331: after every step, if new[0] > threshold, subtract the minimum over all states.  State 0 is position 0 in
+// every phase: lane 0.  With the lazy offset: the test is shifted by off, and the subtraction is off = minimum.
 template <class C>
-__device__ __forceinline__ void renormalise(unsigned &M) {
+__device__ __forceinline__ void renormalise(unsigned &M, Lazy &lz) {
     if constexpr (C::renorm) {
         const unsigned m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)M);
-        if (m0 > (((unsigned)C::renorm_thr << 24) | 0x00ffffffu)) M -= wave_min_u32(M) & 0xff000000u;
+        if (m0 > (unsigned)C::renorm_thr + lz.off) {
+            lz.off = wave_min_u32(M);
+            lz.cap = lz.off + 255u;
+        }
+    }
+}
+// off grows by at most 63 per step; once per block of steps it is folded back into the registers long before it can wrap
+template <class C, int NM>
+__device__ __forceinline__ void fold_offset(unsigned (&M)[NM], Lazy &lz) {
+    if constexpr (C::renorm) {
+        if (lz.off > (1u << 30)) {
+#pragma unroll
+            for (int r = 0; r < NM; r++) M[r] -= lz.off;
+            lz.off = 0;
+            lz.cap = 255u;
+        }
     }
 }
 
@@ -164,7 +200,10 @@ __global__ __launch_bounds__(THREADS) void acs_wave_kernel(Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char tbl[2][TBL_BYTES];
 
     const int f = blockIdx.x;
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    // the wave index as a SCALAR: "wave == 0" must be a uniform branch for the compiler, or every scalar the worker wave carries from
+    // step to step (the lazy offset of the spiral arithmetic) becomes a per-lane value under a divergent branch
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const unsigned char *syms = a.syms + (size_t)f * a.sym_stride;
     unsigned long long *rows = a.dec + (size_t)f * a.cap_rows + a.row0;
     const int phi0 = a.row0 % NB;
@@ -183,13 +222,14 @@ __global__ __launch_bounds__(THREADS) void acs_wave_kernel(Args a) {
 #pragma unroll
             for (int cl = 0; cl < NC; cl++) {
                 const int t = C::bm(s, (unsigned)cl);
-                e[cl] = make_uint2((unsigned)t << 24, (unsigned)C::bm_tc(t) << 24);
+                e[cl] = make_uint2((unsigned)t << metric_shift<C>(), (unsigned)C::bm_tc(t) << metric_shift<C>());
             }
         }
     };
 
     // ---- wave 0: the serial chain
     unsigned M = 0;
+    Lazy lz;
     unsigned cls[NB];     // class of this lane's butterfly at each phase
     bool up[NB];          // this lane is the upper predecessor at each phase
     unsigned aoff[NB];    // byte offset of the class entry inside a step's record
@@ -214,10 +254,10 @@ __global__ __launch_bounds__(THREADS) void acs_wave_kernel(Args a) {
             constexpr int PHI = decltype(P)::value;
             if (phi == PHI) {  // uniform
                 const int t = C::bm(s, cls[PHI]);
-                d = step<C, PHI>(M, (unsigned)t << 24, (unsigned)C::bm_tc(t) << 24, up[PHI], lane);
+                d = step<C, PHI>(M, (unsigned)t << metric_shift<C>(), (unsigned)C::bm_tc(t) << metric_shift<C>(), up[PHI], lane, lz);
             }
         });
-        renormalise<C>(M);
+        renormalise<C>(M, lz);
         const unsigned long long row = __builtin_amdgcn_ballot_w64(d);
         if (lane == 0) rows[i] = row;
     };
@@ -235,6 +275,11 @@ __global__ __launch_bounds__(THREADS) void acs_wave_kernel(Args a) {
             for (int b0 = 0; b0 < cnt; b0 += BLK) {
                 unsigned acc_lo = 0, acc_hi = 0;
                 const unsigned char *blk = tb + b0 * STEP_BYTES;
+                {
+                    unsigned m1[1] = {M};
+                    fold_offset<C, 1>(m1, lz);
+                    M = m1[0];
+                }
                 // the table entries of a whole period are fetched one period ahead: an LDS read issued a step ahead is not back in
                 // time for a ~90-cycle step
                 uint2 en[NB];
@@ -244,8 +289,8 @@ __global__ __launch_bounds__(THREADS) void acs_wave_kernel(Args a) {
                     constexpr int j = decltype(J)::value, PHI = j % NB;
                     const uint2 e = en[PHI];
                     if constexpr (j + NB < BLK) en[PHI] = *reinterpret_cast<const uint2 *>(blk + aoff[PHI] + (j + NB) * STEP_BYTES);
-                    const bool d = step<C, PHI>(M, e.x, e.y, up[PHI], lane);
-                    renormalise<C>(M);
+                    const bool d = step<C, PHI>(M, e.x, e.y, up[PHI], lane, lz);
+                    renormalise<C>(M, lz);
                     const unsigned long long row = __builtin_amdgcn_ballot_w64(d);
                     acc_lo = writelane<j>(acc_lo, (unsigned)row);
                     acc_hi = writelane<j>(acc_hi, (unsigned)(row >> 32));
@@ -260,7 +305,7 @@ __global__ __launch_bounds__(THREADS) void acs_wave_kernel(Args a) {
     if (wave == 0) {
         for (int i = pre + nmain; i < a.nsteps; i++) slow_step(i);
         // position p now holds state rotl^((row0 + nsteps) mod 6)(p)
-        a.metrics[(size_t)f * N + rotl6(lane, (a.row0 + a.nsteps) % NB)] = (int16_t)(M >> 24);
+        a.metrics[(size_t)f * N + rotl6(lane, (a.row0 + a.nsteps) % NB)] = (int16_t)from_lane_metric<C>(M, lz);
     }
 }
 
@@ -284,16 +329,19 @@ __host__ __device__ constexpr unsigned rotl8(unsigned x, int s) {
 template <class C>
 __global__ __launch_bounds__(256) void acs_wave9_kernel(Args a) {
     using namespace k9;
+    static_assert(C::metric == U8MOD && !C::renorm, "ka9q arithmetic: the spiral codes take acs_wave9s_kernel (their per-step minimum would need a barrier per step here)");
     constexpr int R = C::R, NC = 1 << R;
     constexpr int STEP_BYTES = NC * 8;
     constexpr int CH = (TBL_BYTES / STEP_BYTES / BLK) * BLK;
     static_assert(BLK % k9::NB == 0 && CH >= BLK, "a block is whole periods");
     __shared__ __attribute__((aligned(16))) unsigned char tbl[TBL_BYTES];
     __shared__ unsigned xchg[2][4][64];   // wave-bit phases: every wave's metrics, buffer = phase
-    __shared__ unsigned red[2][8];        // spiral: per-wave minima [0..3], wave 0's "new[0] > threshold" [4]; buffer = step parity
 
     const int f = blockIdx.x;
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    // the wave index as a SCALAR: "wave == 0" must be a uniform branch for the compiler, or every scalar the worker wave carries from
+    // step to step (the lazy offset of the spiral arithmetic) becomes a per-lane value under a divergent branch
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const unsigned char *syms = a.syms + (size_t)f * a.sym_stride;
     unsigned long long *rows = a.dec + ((size_t)f * a.cap_rows + a.row0) * 4 + wave;  // this wave's column; row stride 4 words
     const int phi0 = a.row0 % k9::NB;
@@ -311,7 +359,7 @@ __global__ __launch_bounds__(256) void acs_wave9_kernel(Args a) {
         aoff[p] = cls[p] * 8u;
     }
     unsigned M = to_lane_metric<C>(a.metrics[(size_t)f * k9::N + rotl8(tid, phi0)]);
-    int parity = 0;  // of the step, for the renormalisation buffers
+    const Lazy lz;  // unused by the modular arithmetic
 
     // partner of this lane at phase PHI (uniform): lane bits through the K=7 partner fetch, wave bits through LDS
     auto fetch = [&](auto P) -> unsigned {
@@ -322,19 +370,6 @@ __global__ __launch_bounds__(256) void acs_wave9_kernel(Args a) {
             xchg[PHI][wave][lane] = M;
             __syncthreads();
             return xchg[PHI][wave ^ (PHI == 0 ? 2u : 1u)][lane];
-        }
-    };
-    auto renorm = [&]() {
-        if constexpr (C::renorm) {
-            const unsigned mn = wave_min_u32(M);
-            if (lane == 0) {
-                red[parity][wave] = mn;
-                if (wave == 0) red[parity][4] = M > (((unsigned)C::renorm_thr << 24) | 0x00ffffffu);  // state 0 = position 0
-            }
-            __syncthreads();
-            const unsigned *rd = red[parity];
-            if (rd[4]) M -= min(min(rd[0], rd[1]), min(rd[2], rd[3])) & 0xff000000u;
-            parity ^= 1;
         }
     };
     auto slow_step = [&](int i) {
@@ -348,10 +383,9 @@ __global__ __launch_bounds__(256) void acs_wave9_kernel(Args a) {
             if (phi == PHI) {  // uniform
                 const int t = C::bm(s, cls[PHI]);
                 const unsigned X = fetch(P);
-                d = acs<C>(M, X, (unsigned)t << 24, (unsigned)C::bm_tc(t) << 24, up[PHI]);
+                d = acs<C>(M, X, (unsigned)t << 24, (unsigned)C::bm_tc(t) << 24, up[PHI], lz);
             }
         });
-        renorm();
         const unsigned long long row = __builtin_amdgcn_ballot_w64(d);
         if (lane == 0) rows[(size_t)i * 4] = row;
     };
@@ -383,8 +417,7 @@ __global__ __launch_bounds__(256) void acs_wave9_kernel(Args a) {
                 const uint2 e = en[PHI];
                 if constexpr (j + k9::NB < BLK) en[PHI] = *reinterpret_cast<const uint2 *>(blk + aoff[PHI] + (j + k9::NB) * STEP_BYTES);
                 const unsigned X = fetch(std::integral_constant<int, PHI>{});
-                const bool d = acs<C>(M, X, e.x, e.y, up[PHI]);
-                renorm();
+                const bool d = acs<C>(M, X, e.x, e.y, up[PHI], lz);
                 const unsigned long long row = __builtin_amdgcn_ballot_w64(d);
                 acc_lo = writelane<j>(acc_lo, (unsigned)row);
                 acc_hi = writelane<j>(acc_hi, (unsigned)(row >> 32));
@@ -413,7 +446,10 @@ __global__ __launch_bounds__(THREADS) void acs_wave9s_kernel(Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char tbl[2][TBL_BYTES];
 
     const int f = blockIdx.x;
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    // the wave index as a SCALAR: "wave == 0" must be a uniform branch for the compiler, or every scalar the worker wave carries from
+    // step to step (the lazy offset of the spiral arithmetic) becomes a per-lane value under a divergent branch
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const unsigned char *syms = a.syms + (size_t)f * a.sym_stride;
     unsigned long long *rows = a.dec + ((size_t)f * a.cap_rows + a.row0) * 4;
     const int phi0 = a.row0 % k9::NB;
@@ -431,12 +467,13 @@ __global__ __launch_bounds__(THREADS) void acs_wave9s_kernel(Args a) {
 #pragma unroll
             for (int cl = 0; cl < NC; cl++) {
                 const int t = C::bm(s, (unsigned)cl);
-                e[cl] = make_uint2((unsigned)t << 24, (unsigned)C::bm_tc(t) << 24);
+                e[cl] = make_uint2((unsigned)t << metric_shift<C>(), (unsigned)C::bm_tc(t) << metric_shift<C>());
             }
         }
     };
 
     unsigned M[4] = {0, 0, 0, 0};
+    Lazy lz;
     unsigned cls[k9::NB][4], aoff[k9::NB][4];
     bool up[k9::NB];  // phases 2..7: this lane holds the upper predecessor (the same for its four registers)
     if (wave == 0) {
@@ -458,23 +495,22 @@ __global__ __launch_bounds__(THREADS) void acs_wave9s_kernel(Args a) {
         constexpr int PHI = decltype(P)::value;
         if constexpr (PHI >= 2) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) d[r] = acs<C>(M[r], partner<k9::NB - 1 - PHI>(M[r], lane), e[r].x, e[r].y, up[PHI]);
+            for (int r = 0; r < 4; r++) d[r] = acs<C>(M[r], partner<k9::NB - 1 - PHI>(M[r], lane), e[r].x, e[r].y, up[PHI], lz);
         } else {
             constexpr int S = PHI == 0 ? 2 : 1;  // partner register: r ^ 2 (position bit 7) or r ^ 1 (bit 6)
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 const int lo = PHI == 0 ? k : 2 * k, hi = lo + S;
                 const unsigned old_lo = M[lo], old_hi = M[hi];
-                d[lo] = acs<C>(M[lo], old_hi, e[lo].x, e[lo].y, false);
-                d[hi] = acs<C>(M[hi], old_lo, e[hi].x, e[hi].y, true);
+                d[lo] = acs<C>(M[lo], old_hi, e[lo].x, e[lo].y, false, lz);
+                d[hi] = acs<C>(M[hi], old_lo, e[hi].x, e[hi].y, true, lz);
             }
         }
-        if constexpr (C::renorm) {  // state 0 is position 0: register 0 of lane 0
+        if constexpr (C::renorm) {  // state 0 is position 0: register 0 of lane 0; lazy offset as in renormalise()
             const unsigned m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)M[0]);
-            if (m0 > (((unsigned)C::renorm_thr << 24) | 0x00ffffffu)) {
-                const unsigned mn = wave_min_u32(min(min(M[0], M[1]), min(M[2], M[3]))) & 0xff000000u;
-#pragma unroll
-                for (int r = 0; r < 4; r++) M[r] -= mn;
+            if (m0 > (unsigned)C::renorm_thr + lz.off) {
+                lz.off = wave_min_u32(min(min(M[0], M[1]), min(M[2], M[3])));
+                lz.cap = lz.off + 255u;
             }
         }
     };
@@ -491,7 +527,7 @@ __global__ __launch_bounds__(THREADS) void acs_wave9s_kernel(Args a) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int t = C::bm(s, cls[PHI][r]);
-                    e[r] = make_uint2((unsigned)t << 24, (unsigned)C::bm_tc(t) << 24);
+                    e[r] = make_uint2((unsigned)t << metric_shift<C>(), (unsigned)C::bm_tc(t) << metric_shift<C>());
                 }
                 step9(P, e, d);
             }
@@ -516,6 +552,7 @@ __global__ __launch_bounds__(THREADS) void acs_wave9s_kernel(Args a) {
             for (int b0 = 0; b0 < cnt; b0 += BLK) {
                 unsigned acc[4][2] = {};
                 const unsigned char *blk = tb + b0 * STEP_BYTES;
+                fold_offset<C, 4>(M, lz);
                 uint2 en[k9::NB][4];  // table entries fetched one period ahead (see acs_wave_kernel)
 #pragma unroll
                 for (int q = 0; q < k9::NB; q++)
@@ -553,7 +590,7 @@ __global__ __launch_bounds__(THREADS) void acs_wave9s_kernel(Args a) {
         for (int i = pre + nmain; i < a.nsteps; i++) slow_step(i);
 #pragma unroll
         for (int r = 0; r < 4; r++)
-            a.metrics[(size_t)f * k9::N + rotl8((unsigned)r * 64u + lane, (a.row0 + a.nsteps) % k9::NB)] = (int16_t)(M[r] >> 24);
+            a.metrics[(size_t)f * k9::N + rotl8((unsigned)r * 64u + lane, (a.row0 + a.nsteps) % k9::NB)] = (int16_t)from_lane_metric<C>(M[r], lz);
     }
 }
 
