@@ -379,6 +379,61 @@ def run_extra_config(base_args, code, steps, warmup, cpu_budget, dev):
         torch.cuda.empty_cache()
 
 
+# The reference's OWN measurement (src/main.cpp:264-278: one frame per call, host buffers, each of the three calls timed by
+# itself) through the five-function C ABI that replaces its decoders -- the geometry a maintainer sees after swapping the
+# library in without batching anything.  Not a throughput claim: one frame cannot fill the chip, these are latency figures.
+ONE_FRAME_HANDLES = [("27", "viterbi27", "_blk"), ("47", "spiral47", ""), ("29", "viterbi29", "_blk"), ("49", "spiral49", ""),
+                     ("615", "viterbi615", "_blk"), ("224", "viterbi224", "_blk")]
+
+
+def one_frame_handles(budget_s=0.4):
+    from ka9q_viterbi_comparison_amd import _lib
+
+    lib = _lib.load()
+    rows = []
+    for code, stem, blk in ONE_FRAME_HANDLES:
+        spec = C.CODES[code]
+        nbits = spec.ref_payload_bytes * 8  # the reference's frame for this decoder (main.cpp:364-418)
+        steps = nbits + spec.K - 1
+        payload, syms = gen_frames_host(spec, 77, 0, 1, spec.ref_payload_bytes, C.SOFT_AMP_Q16, noise_q12(spec.R, 64.0, spec.ebn0_db))
+        create, init = getattr(lib, f"create_{stem}_hip"), getattr(lib, f"init_{stem}_hip")
+        update, chainback, delete = getattr(lib, f"update_{stem}{blk}_hip"), getattr(lib, f"chainback_{stem}_hip"), getattr(lib, f"delete_{stem}_hip")
+        poly = (ctypes.c_int * spec.R)(*spec.poly)
+        h = create(poly, steps)  # the reference creates with the transmit length (main.cpp:247)
+        if not h:
+            rows.append({"code": code, "error": _lib.last_error()})
+            continue
+        try:
+            out = np.zeros(spec.ref_payload_bytes, dtype=np.uint8)
+            sp, op = syms.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)
+            t_upd = t_cb = 0.0
+            n = 0
+            t_end = time.perf_counter() + budget_s
+            for it in range(-2, 100000):  # two untimed passes first
+                init(h, 0)
+                t0 = time.perf_counter()
+                update(h, sp, steps)
+                t1 = time.perf_counter()
+                chainback(h, op, nbits, 0)
+                t2 = time.perf_counter()
+                if it >= 0:
+                    t_upd, t_cb, n = t_upd + (t1 - t0), t_cb + (t2 - t1), n + 1
+                    if t2 > t_end and n >= 3:
+                        break
+            if spec.K == 24:
+                # chainback_viterbi224 does not skip the tail rows: the payload comes out of the nbits+K-1 call
+                long_out = np.zeros((steps + 7) // 8, dtype=np.uint8)
+                chainback(h, long_out.ctypes.data_as(ctypes.c_void_p), steps, 0)
+                out = long_out[:spec.ref_payload_bytes]
+            errors = int(np.unpackbits(out ^ payload[0]).sum())
+            rows.append({"code": code, "K": spec.K, "R": spec.R, "payload_bits": nbits, "decodes": n, "bit_errors": errors,
+                         "update_msym_s": round(steps * spec.R * n / t_upd / 1e6, 3), "update_ms": round(t_upd / n * 1e3, 4),
+                         "chainback_mbit_s": round(nbits * n / t_cb / 1e6, 3), "chainback_ms": round(t_cb / n * 1e3, 4)})
+        finally:
+            delete(h)
+    return rows
+
+
 # BASELINE.json configs: K=7 x 65536 frames, K=15 x 4096 frames, K=24 single long frame; K=9 sized in between
 DEFAULT_FRAMES = {7: 65536, 9: 32768, 15: 4096, 24: 1}
 
@@ -459,6 +514,14 @@ def main():
         out["extra"] = {"note": "BASELINE.json configs[2] (K=15 x 4096 frames) and configs[3] (K=24, one 2048-bit frame), measured after the "
                                 "headline in the same process: same fields, fewer steps, a shorter CPU sample",
                         "configs": extras}
+        try:
+            out["extra"]["one_frame_handles"] = {
+                "note": "the reference's own measurement (src/main.cpp:264-278): ONE frame of its size per call through the five-function "
+                        "C ABI with host buffers, update and chainback timed separately around the blocking calls (PCIe copies and "
+                        "launch latency included) -- latency figures for an unbatched drop-in, not throughput",
+                "decoders": one_frame_handles()}
+        except Exception as e:  # noqa: BLE001
+            out["extra"]["one_frame_handles"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -60,3 +60,11 @@ def test_bench_default_line_carries_every_single_gpu_config():
         assert e["roofline"]["bytes_per_launch"] > 0 and e["roofline"]["algorithmic_bytes_per_launch"] > 0
     assert "4096 frames" in extras[0]["config"]["workload"] and extras[0]["dtype"] == "i16"
     assert "1 frames" in extras[1]["config"]["workload"] and extras[1]["bit_errors"] == 0  # K=24 at 4 dB: error free
+    # the reference's own methodology (one frame per call, host buffers) through the five-function C ABI, per decoder
+    one = d["extra"]["one_frame_handles"]
+    assert "error" not in one, one
+    assert [r["code"] for r in one["decoders"]] == ["27", "47", "29", "49", "615", "224"]
+    for r in one["decoders"]:
+        assert "error" not in r, r
+        assert r["decodes"] >= 3 and r["update_msym_s"] > 0 and r["chainback_mbit_s"] > 0
+    assert one["decoders"][-1]["bit_errors"] == 0
