@@ -96,21 +96,25 @@ __device__ __forceinline__ void put_signs(i16x2 we, i16x2 wo, unsigned (&acc)[NA
     acc[RE >> 4] = (P & sm.m[i8]) | acc[RE >> 4];
 }
 
-// spiral615 flavour (spiral/spiral615.cpp:220-227): u8 saturating metrics held as (m<<8)|0xff in 16-bit fields so that
-// v_pk_add_u16 clamp == adds_epu8; decision = (min == upper); acc collects the COMPLEMENT at bit KB / 16+KB (KB = 1..8,
-// the min(z, 1<<KB) trick of acs_regs.hip needs z >= 256 whenever it is non-zero).
+// spiral615 flavour (spiral/spiral615.cpp:220-227): u8 saturating metrics held as (m<<7)|0x7f in SIGNED 16-bit fields so that
+// v_pk_add_i16 clamp == adds_epu8 at the top (255 <-> 0x7fff) while the branch metric may be negative: the minimum that
+// renormalize() subtracts after step n (spiral615.cpp:31-40) is folded into the branch metrics of step n+1 instead
+// ("pending", see sp_field / the step loop) -- (m - min) + t == m + (t - min), and m >= min keeps the bottom clamp out of it.
+// decision = (min == upper); acc collects the COMPLEMENT at bit KB / 16+KB (KB = 0..7: the min(z, 1<<KB) trick of
+// acs_regs.hip needs z >= 1<<KB whenever it is non-zero, and differences are multiples of 128).
+constexpr unsigned sp_field(unsigned m) { return (m << 7) | 0x7fu; }
 template <int KB>
 __device__ __forceinline__ i16x2 acs_u8(i16x2 lower, i16x2 upper, unsigned &acc) {
     const u16x2 lo = (u16x2)lower, up = (u16x2)upper;
     const u16x2 z = __builtin_elementwise_sub_sat(up, lo);  // 0 <=> upper <= lower <=> decision 1
-    const u16x2 one = {(unsigned short)(1u << KB), (unsigned short)(1u << KB)};
-    acc |= __builtin_bit_cast(unsigned, __builtin_elementwise_min(z, one));
+    unsigned bit = 0x10001u << KB;
+    if constexpr (KB == 0) asm("" : "+s"(bit));  // min(z, 1) as a constant is turned into compare + select + perm
+    acc |= __builtin_bit_cast(unsigned, __builtin_elementwise_min(z, __builtin_bit_cast(u16x2, bit)));
     return (i16x2)__builtin_elementwise_min(lo, up);
 }
 template <bool SP>
 __device__ __forceinline__ i16x2 madd(i16x2 a, unsigned t) {
-    if constexpr (SP) return (i16x2)__builtin_elementwise_add_sat((u16x2)a, __builtin_bit_cast(u16x2, t));  // adds_epu8
-    else return __builtin_elementwise_add_sat(a, as_v(t));                                                   // adds_epi16
+    return __builtin_elementwise_add_sat(a, as_v(t));  // adds_epi16; spiral: adds_epu8 in the (m<<7)|0x7f fields
 }
 
 // Branch-table class offset of this thread's thread-id bits at phase PHI (linear in GF(2); folded into the symbols as a
@@ -148,9 +152,11 @@ struct ClassOffsets {
     }
 };
 
-// One trellis step at phase PHI on the 128 positions this thread holds.  SP selects the spiral615 arithmetic.
+// One trellis step at phase PHI on the 128 positions this thread holds.  SP selects the spiral615 arithmetic; `pend` is the
+// minimum the previous step's renormalisation still owes (spiral615 only, workgroup-uniform, 0..255).
 template <bool SP, int PHI>
-__device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R], const ClassOffsets &co, unsigned (&words)[4], const SignMasks &sm) {
+__device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R], const ClassOffsets &co, unsigned (&words)[4], const SignMasks &sm,
+                                      unsigned pend = 0) {
     constexpr int b = NB - 1 - PHI;            // position bit paired in this phase
     constexpr bool GA = b >= 7;                // group A: free bits 7..13, thread bits 0..6; group B: the reverse
     constexpr int kf = GA ? b - 7 : b;         // local free-bit index of the paired bit (0 = the half bit)
@@ -183,14 +189,19 @@ __device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R],
     }
     unsigned acc[SP ? 8 : 4] = {};
     constexpr unsigned COMP = SP ? 94u : (unsigned)Code615::bm_comp;
+    // spiral615: (t - pend) << 7 and (94 - t - pend) << 7 as wrapping 16-bit fields = t * (+-128) + these two (v_pk_mad_u16)
+    const unsigned short spn = (unsigned short)((0u - pend) << 7), spq = (unsigned short)((COMP - pend) << 7);
+    unsigned mul_up = 0x00800080u, mul_dn = 0xff80ff80u;  // +-128 per field, opaque: as constants the multiply becomes a shift and
+    asm("" : "+s"(mul_up), "+s"(mul_dn));                 // the v_pk_mad_u16 two instructions
     // branch-metric fields of a register pair from the table sums (both 16-bit fields at once)
     auto fields = [&](unsigned sum, unsigned &tp, unsigned &tq) {
         if constexpr (SP) {
             // adds_epu8 chain saturates at 255, then (>>2)&63: t = min(63, sum>>2); t' = subs_epu8(94, t)   spiral615.cpp:216-242
-            const u16x2 c63 = {63, 63};
+            // (94 - t >= 31 > 0: that saturating subtract never clamps); both minus the pending minimum
+            const u16x2 c63 = {63, 63}, up = __builtin_bit_cast(u16x2, mul_up), dn = __builtin_bit_cast(u16x2, mul_dn), vn = {spn, spn}, vq = {spq, spq};
             const u16x2 t = __builtin_elementwise_min((u16x2)(__builtin_bit_cast(u16x2, sum) >> 2), c63);
-            tp = __builtin_bit_cast(unsigned, (u16x2)(t << 8));
-            tq = (COMP << 8) * 0x10001u - tp;  // 94 - t >= 31 > 0: the saturating subtract never clamps
+            tp = __builtin_bit_cast(unsigned, (u16x2)(t * up + vn));
+            tq = __builtin_bit_cast(unsigned, (u16x2)(t * dn + vq));
         } else {
             tp = sum;                          // both fields <= 1530: no carry between them
             tq = COMP * 0x10001u - tp;         // t' = 1530 - t in both fields
@@ -216,8 +227,8 @@ __device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R],
             const i16x2 A = M[r0], B = M[r1];
             const i16x2 m0 = madd<SP>(A, tp), m1 = madd<SP>(B, tq), m2 = madd<SP>(A, tq), m3 = madd<SP>(B, tp);
             if constexpr (SP) {
-                M[r0] = acs_u8<(r0 & 7) + 1>(m0, m1, acc[r0 >> 3]);
-                M[r1] = acs_u8<(r1 & 7) + 1>(m2, m3, acc[r1 >> 3]);
+                M[r0] = acs_u8<(r0 & 7)>(m0, m1, acc[r0 >> 3]);
+                M[r1] = acs_u8<(r1 & 7)>(m2, m3, acc[r1 >> 3]);
             } else {
                 M[r0] = acs(m0, m1, W0);
                 M[r1] = acs(m2, m3, W1);
@@ -265,7 +276,7 @@ __device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R],
             const i16x2 Alo = {A.x, A.x}, Ahi = {A.y, A.y};
             const i16x2 lower = madd<SP>(Alo, t | (tc << 16));  // (m0, m2) = old[j] + (t, t')
             const i16x2 upper = madd<SP>(Ahi, tc | (t << 16));  // (m1, m3) = old[j+H] + (t', t)
-            if constexpr (SP) M[r0] = acs_u8<(r0 & 7) + 1>(lower, upper, acc[r0 >> 3]);
+            if constexpr (SP) M[r0] = acs_u8<(r0 & 7)>(lower, upper, acc[r0 >> 3]);
             else M[r0] = acs(lower, upper, W);
         };
         sfor<NR / 2>([&](auto I) {
@@ -278,7 +289,7 @@ __device__ __forceinline__ void stage(i16x2 (&M)[NR], const unsigned (&sraw)[R],
     }
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-        if constexpr (SP) words[w] = ~((acc[2 * w] >> 1) | (acc[2 * w + 1] << 7));  // accumulators use bits 1..8 / 17..24
+        if constexpr (SP) words[w] = ~(acc[2 * w] | (acc[2 * w + 1] << 8));  // accumulators use bits 0..7 / 16..23
         else words[w] = ~acc[w];
     }
 }
@@ -377,10 +388,10 @@ __device__ __forceinline__ void acs_k15_body(const Args &a) {
         row_end = a.nsteps;
         phi0 = 0;
         ring = a.ring + (long)blockIdx.x * WIN_RING * 512;
-        // init_viterbi615_sse2 (viterbi615_sse2.cpp:33-39): every state init_all, state 0 init_start; spiral: (m<<8)|0xff fields
+        // init_viterbi615_sse2 (viterbi615_sse2.cpp:33-39): every state init_all, state 0 init_start; spiral: (m<<7)|0x7f fields
         using CT = std::conditional_t<SP, Spiral615, Code615>;
-        const int ia = SP ? (int)(((unsigned)CT::init_all << 8) | 0xffu) : CT::init_all;
-        const int is = SP ? (int)(((unsigned)CT::init_start << 8) | 0xffu) : CT::init_start;
+        const int ia = SP ? (int)sp_field((unsigned)CT::init_all) : CT::init_all;
+        const int is = SP ? (int)sp_field((unsigned)CT::init_start) : CT::init_start;
         __syncthreads();  // the previous frame's last reads of the image are done
         for (unsigned p = tid; p < (unsigned)N; p += THREADS) sm.img[img_at(p)] = (int16_t)(p == 0 ? is : ia);
     } else {
@@ -390,7 +401,7 @@ __device__ __forceinline__ void acs_k15_body(const Args &a) {
         gm = a.metrics + f * (long)N;
         for (unsigned p = tid; p < (unsigned)N; p += THREADS) {
             const unsigned st = phi0 == 0 ? p : (((p << phi0) | (p >> (NB - phi0))) & (N - 1u));
-            sm.img[img_at(p)] = SP ? (int16_t)(((unsigned)gm[st] << 8) | 0xffu) : gm[st];  // spiral: (m<<8)|0xff fields
+            sm.img[img_at(p)] = SP ? (int16_t)sp_field((unsigned)gm[st] & 255u) : gm[st];  // spiral: (m<<7)|0x7f fields
         }
         drow = reinterpret_cast<unsigned *>(a.dec) + (f * a.cap_rows + row0) * 512L + tid;
     }
@@ -398,6 +409,7 @@ __device__ __forceinline__ void acs_k15_body(const Args &a) {
     const long lim = (long)a.nsteps * R;
     const bool aligned = ((reinterpret_cast<uintptr_t>(a.syms) | a.sym_stride) & 3) == 0 && ((phi0 * R) & 3) == 0;
     unsigned nextb = 0;  // WIN: next block to emit
+    unsigned pend = 0;   // spiral615: the minimum the last renormalisation owes, subtracted inside the next step's branch metrics
     __syncthreads();
 
     i16x2 M[NR];
@@ -467,7 +479,7 @@ __device__ __forceinline__ void acs_k15_body(const Args &a) {
                         sraw[q] = (cur[idx >> 2] >> (8 * (idx & 3))) & 255u;
                     }
                     unsigned words[4];
-                    stage<SP, PHI>(M, sraw, co, words, sgm);
+                    stage<SP, PHI>(M, sraw, co, words, sgm, pend);
                     if constexpr (WIN) {
                         unsigned *rr = ring + (long)(r % WIN_RING) * 512 + tid;
 #pragma unroll
@@ -478,21 +490,20 @@ __device__ __forceinline__ void acs_k15_body(const Args &a) {
                         drow += 512;
                     }
                     if constexpr (SP) {
-                        // spiral615.cpp:31-40,269: if new[0] > 74 subtract the minimum -- it fires on nearly every step,
-                        // so the workgroup minimum is formed unconditionally behind the one barrier of the step
-                        u16x2 mn = (u16x2)M[0];
+                        // spiral615.cpp:31-40,269: if new[0] > 74 subtract the minimum -- it fires on nearly every step, so
+                        // the workgroup minimum is formed unconditionally behind the one barrier of the step.  Nothing is
+                        // subtracted here: the registers keep this step's values and the next step's branch metrics carry
+                        // the minimum (64 v_pk_sub per thread and step saved); the final store below settles the last one.
+                        u16x2 mq[4] = {(u16x2)M[0], (u16x2)M[1], (u16x2)M[2], (u16x2)M[3]};  // four chains: a single one is 63 dependent instructions
 #pragma unroll
-                        for (int i = 1; i < NR; i++) mn = __builtin_elementwise_min(mn, (u16x2)M[i]);
+                        for (int i = 4; i < NR; i++) mq[i & 3] = __builtin_elementwise_min(mq[i & 3], (u16x2)M[i]);
+                        const u16x2 mn = __builtin_elementwise_min(__builtin_elementwise_min(mq[0], mq[1]), __builtin_elementwise_min(mq[2], mq[3]));
                         const unsigned m = wave_min(min((unsigned)mn.x, (unsigned)mn.y));
                         if ((tid & 63u) == 0) sm.red[2 * (r & 1) + (tid >> 6)] = (int)m;
-                        if (tid == 0) sm.flag[r & 1] = (as_u32(M[0]) & 0xffffu) > ((74u << 8) | 0xffu);
+                        if (tid == 0) sm.flag[r & 1] = (as_u32(M[0]) & 0xffffu) > sp_field((unsigned)Spiral615::renorm_thr);
                         __syncthreads();
-                        if (sm.flag[r & 1]) {
-                            const unsigned amt = (unsigned)min(sm.red[2 * (r & 1)], sm.red[2 * (r & 1) + 1]) & 0xff00u;
-                            const u16x2 av = {(unsigned short)amt, (unsigned short)amt};
-#pragma unroll
-                            for (int i = 0; i < NR; i++) M[i] = (i16x2)__builtin_elementwise_sub_sat((u16x2)M[i], av);
-                        }
+                        const unsigned owed = sm.flag[r & 1] ? (unsigned)min(sm.red[2 * (r & 1)], sm.red[2 * (r & 1) + 1]) >> 7 : 0u;
+                        pend = (unsigned)__builtin_amdgcn_readfirstlane((int)owed);
                     } else {
                     // renormalise when new[0] >= SHRT_MAX-12750; state 0 is position 0 = thread 0, register 0, low field
                     if (tid == 0) sm.flag[r & 1] = ((int)(short)(as_u32(M[0]) & 0xffffu)) >= Code615::renorm_thr;
@@ -563,7 +574,7 @@ __device__ __forceinline__ void acs_k15_body(const Args &a) {
         const int phie = row_end % NB;
         for (unsigned p = tid; p < (unsigned)N; p += THREADS) {
             const unsigned st = phie == 0 ? p : (((p << phie) | (p >> (NB - phie))) & (N - 1u));
-            gm[st] = SP ? (int16_t)(((unsigned)(unsigned short)sm.img[img_at(p)]) >> 8) : sm.img[img_at(p)];
+            gm[st] = SP ? (int16_t)((((unsigned)(unsigned short)sm.img[img_at(p)]) >> 7) - pend) : sm.img[img_at(p)];
         }
     }
   }
