@@ -91,26 +91,32 @@ struct RegsCfg {
     static_assert((NB * R) % 4 == 0 && NR >= 8 && (NR % 8) == 0, "unsupported geometry");
 };
 
-// packed metric field <-> natural value
+// packed metric field <-> natural value.  Modular family: m << 8 (the byte wraps with the field).  Saturating family: the
+// SIGNED field (m << 7) | 0x7f -- v_pk_add_i16 clamp saturates where adds_epu8 does (255 <-> 0x7fff) and the addend may be
+// negative, which lets the renormalisation's subtract ride in the next step's branch metrics (RegsStep::run, `pend`).
 template <bool SAT>
-__device__ __forceinline__ unsigned field_from(int m) { return SAT ? (((unsigned)m << 8) | 0xffu) : ((unsigned)m << 8); }
-__device__ __forceinline__ int field_to(unsigned f) { return (int)((f >> 8) & 0xffu); }
+__device__ __forceinline__ constexpr unsigned field_from(int m) { return SAT ? (((unsigned)m << 7) | 0x7fu) : ((unsigned)m << 8); }
+template <bool SAT>
+__device__ __forceinline__ int field_to(unsigned f) { return (int)((f >> (SAT ? 7 : 8)) & 0xffu); }
 
 template <bool SAT>
 __device__ __forceinline__ u16x2 madd(u16x2 a, u16x2 t) {
-    if constexpr (SAT) return __builtin_elementwise_add_sat(a, t);  // v_pk_add_u16 clamp == adds_epu8 on the high byte
-    else return a + t;                                               // v_pk_add_u16 wrap  == add_epi8  on the high byte
+    if constexpr (SAT) return (u16x2)__builtin_elementwise_add_sat((i16x2)a, (i16x2)t);  // v_pk_add_i16 clamp == adds_epu8 on bits 7..14
+    else return a + t;                                                                    // v_pk_add_u16 wrap  == add_epi8  on the high byte
 }
 
 // One packed add-compare-select: two new states.  `acc` collects decision bit k (low field) / 16+k (high field);
 // for the saturating family the collected bit is the COMPLEMENT of the decision (fixed up once per word).
 template <bool SAT, int KBIT>
 __device__ __forceinline__ u16x2 acs_pk(u16x2 lower, u16x2 upper, unsigned &acc) {
+    static_assert(SAT ? KBIT <= 7 : (KBIT >= 1 && KBIT <= 8), "the collected bit must not exceed the smallest non-zero difference");
     const u16x2 one = {(unsigned short)(1u << KBIT), (unsigned short)(1u << KBIT)};
     if constexpr (SAT) {
         // min_epu8(upper,lower); decision = (min == upper) <=> upper <= lower       spiral47.cpp:224-227
-        const u16x2 z = __builtin_elementwise_sub_sat(upper, lower);  // 0 <=> upper <= lower; else a multiple of 256
-        acc |= as_u32(__builtin_elementwise_min(z, one));
+        const u16x2 z = __builtin_elementwise_sub_sat(upper, lower);  // 0 <=> upper <= lower; else a multiple of 128
+        unsigned bit = 0x10001u << KBIT;
+        if constexpr (KBIT == 0) asm("" : "+s"(bit));  // min(z, 1) with a constant 1 is turned into compare + select + perm
+        acc |= as_u32(__builtin_elementwise_min(z, as_v(bit)));
         return __builtin_elementwise_min(lower, upper);
     } else {
         // decision = (int8)(lower-upper) > 0, survivor = decision ? upper : lower    viterbi27_sse2.cpp:155-158
@@ -133,9 +139,10 @@ __device__ __forceinline__ u16x2 dpp_xor(u16x2 x) {
     else return dpp_quad<0x4E>(x);                     // quad_perm [2,3,0,1]
 }
 
-// branch metrics of one step for all 2^R classes, as a 16-bit field value (t << 8), per lane
+// branch metrics of one step for all 2^R classes, as a 16-bit field value, per lane: t << 8 (modular family), or
+// ((t - pending minimum) << 7) mod 2^16 (saturating family; P = pending minimum << 7)
 template <class C, int NC>
-__device__ __forceinline__ void branch_fields(const unsigned (&s)[C::R], unsigned (&T)[NC]) {
+__device__ __forceinline__ void branch_fields(const unsigned (&s)[C::R], unsigned (&T)[NC], unsigned P) {
     if constexpr (C::metric == U8MOD) {
         // t = ((a0+a1+1)>>1)>>4                                                   viterbi27_sse2.cpp:137-146
         const unsigned x0 = s[0] ^ 255u, x1 = s[1] ^ 255u;
@@ -147,7 +154,7 @@ __device__ __forceinline__ void branch_fields(const unsigned (&s)[C::R], unsigne
         const unsigned x0 = s[0] ^ 255u, x1 = s[1] ^ 255u;
         const unsigned a0[2] = {s[0], x0}, a1[2] = {s[1], x1};
 #pragma unroll
-        for (int c = 0; c < 4; c++) T[c] = (((a0[c & 1] + a1[c >> 1] + 1u) >> 3) & 63u) << 8;
+        for (int c = 0; c < 4; c++) T[c] = (((((a0[c & 1] + a1[c >> 1] + 1u) >> 3) & 63u) << 7) - P) & 0xffffu;
     } else {
         // t = (sum_r ((a_r>>2)&63)) >> 2; (s^255)>>2 == 63-(s>>2)                     spiral47.cpp:164-219
         unsigned g[4], h[4];
@@ -156,22 +163,23 @@ __device__ __forceinline__ void branch_fields(const unsigned (&s)[C::R], unsigne
             g[r] = s[r] >> 2;
             h[r] = g[r] ^ 63u;
         }
+        // floor(sum / 4) - pending == floor((sum - 4 pending) / 4): the pending minimum goes into four partial sums
         unsigned p01[4], p23[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             p01[c] = ((c & 1) ? h[0] : g[0]) + ((c & 2) ? h[1] : g[1]);
-            p23[c] = ((c & 1) ? h[2] : g[2]) + ((c & 2) ? h[3] : g[3]);
+            p23[c] = ((c & 1) ? h[2] : g[2]) + ((c & 2) ? h[3] : g[3]) - (P >> 5);
         }
 #pragma unroll
-        for (int c = 0; c < 16; c++) T[c] = ((p01[c & 3] + p23[c >> 2]) >> 2) << 8;
+        for (int c = 0; c < 16; c++) T[c] = ((p01[c & 3] + p23[c >> 2]) << 5) & 0xff80u;
     }
 }
 
 // Packed branch-metric fields for a register / lane stage: TP[c] = field(t(c)) | field(t(c ^ CH)) << 16.  For the r=1/4
 // spiral code the 16 sums are formed on both fields at once (sums <= 252 per field, no carry between them), which
-// halves the scalar-style arithmetic per class: (sum >> 2) << 8 per field is (sum2 << 6) & 0xff00ff00.
+// halves the scalar-style arithmetic per class: (sum >> 2) << 7 per field is (sum2 << 5) & 0xff80ff80.
 template <class C, int NC, unsigned CH>
-__device__ __forceinline__ void branch_fields_paired(const unsigned (&s)[C::R], const unsigned (&T)[NC], unsigned (&TP)[NC]) {
+__device__ __forceinline__ void branch_fields_paired(const unsigned (&s)[C::R], const unsigned (&T)[NC], unsigned (&TP)[NC], unsigned P) {
     if constexpr (C::metric == U8SAT && C::R == 4) {
         unsigned g[4], h[4];
 #pragma unroll
@@ -179,11 +187,16 @@ __device__ __forceinline__ void branch_fields_paired(const unsigned (&s)[C::R], 
             g[r] = s[r] >> 2;
             h[r] = g[r] ^ 63u;
         }
+        // floor(sum / 4) - pending == floor((sum - 4 pending) / 4): the pending minimum goes into four partial sums, together
+        // with a bias of 2048 that keeps every field sum positive (plain 32-bit adds, no borrow between the fields) and drops
+        // out below: (sum + 2048) << 5 carries the bias into bit 16 of its own field -- bit 0 of the high field, which the
+        // mask clears, or out of the dword
+        const unsigned bias = 2048u - (P >> 5);
         unsigned p01[4], p23[4], x01[4], x23[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             p01[c] = ((c & 1) ? h[0] : g[0]) + ((c & 2) ? h[1] : g[1]);
-            p23[c] = ((c & 1) ? h[2] : g[2]) + ((c & 2) ? h[3] : g[3]);
+            p23[c] = ((c & 1) ? h[2] : g[2]) + ((c & 2) ? h[3] : g[3]) + bias;
         }
 #pragma unroll
         for (int c = 0; c < 4; c++) {
@@ -191,7 +204,7 @@ __device__ __forceinline__ void branch_fields_paired(const unsigned (&s)[C::R], 
             x23[c] = p23[c] | (p23[c ^ (CH >> 2)] << 16);
         }
 #pragma unroll
-        for (int c = 0; c < 16; c++) TP[c] = ((x01[c & 3] + x23[c >> 2]) << 6) & 0xff00ff00u;
+        for (int c = 0; c < 16; c++) TP[c] = ((x01[c & 3] + x23[c >> 2]) << 5) & 0xff80ff80u;
     } else {
 #pragma unroll
         for (int c = 0; c < NC; c++) TP[c] = T[c] | (T[c ^ CH] << 16);
@@ -203,12 +216,17 @@ struct RegsStep {
     using G = RegsCfg<C, P, LB>;
     static constexpr int NB = G::NB, R = G::R, NR = G::NR, NC = G::NC, L = G::L;
     static constexpr bool SAT = G::SAT;
-    static constexpr unsigned COMP2 = ((unsigned)C::bm_comp << 8) * 0x10001u;
+    static constexpr unsigned COMP1 = field_from<false>(C::bm_comp) >> (SAT ? 1 : 0);  // t' = COMP - t, as a field value
+    static constexpr unsigned COMP2 = COMP1 * 0x10001u;
+    static constexpr int KB0 = SAT ? 0 : 1;  // first decision bit collected in a 16-bit field (acs_pk)
 
     // One trellis step at phase PHI (absolute row index mod NB).  M: packed metrics; sraw: this step's R symbols;
-    // lam: lane index inside the frame's lane group; words: decision words of this row.
+    // lam: lane index inside the frame's lane group; words: decision words of this row.  pend (saturating family): the frame
+    // minimum the previous step's renormalisation owes, << 7, in both 16-bit fields; it is subtracted inside this step's branch
+    // metrics -- (m - min) + t == m + (t - min), m >= min -- and replaced by what this step owes.  Whoever reads the metrics
+    // out of the registers settles the last one (acs_regs_body).
     template <int PHI>
-    static __device__ __forceinline__ void run(u16x2 (&M)[NR], const unsigned (&sraw)[R], unsigned lam, unsigned (&words)[G::DW]) {
+    static __device__ __forceinline__ void run(u16x2 (&M)[NR], const unsigned (&sraw)[R], unsigned lam, unsigned (&words)[G::DW], unsigned &pend) {
         constexpr int b = NB - 1 - PHI;  // position bit paired at this phase
         // per-lane class offset from the lane bits of the position (linear in GF(2)); fold it into the symbols
         unsigned s[R];
@@ -224,8 +242,12 @@ struct RegsStep {
 #pragma unroll
             for (int r = 0; r < R; r++) s[r] = sraw[r] ^ (((cl >> r) & 1u) ? 255u : 0u);
         }
+        const unsigned PD = SAT ? (pend & 0xffffu) : 0u;
+        // t' = COMP - t - pending = (COMP - 2 pending) - (t - pending), per field mod 2^16
+        const unsigned CQ1 = SAT ? ((COMP1 - 2u * PD) & 0xffffu) : COMP1, CQ2 = CQ1 * 0x10001u;
+        auto comp_of = [&](unsigned tp) { return SAT ? as_u32(as_v(CQ2) - as_v(tp)) : COMP2 - tp; };
         unsigned T[NC];
-        branch_fields<C, NC>(s, T);
+        branch_fields<C, NC>(s, T, PD);
         unsigned acc[NR / 8];
 #pragma unroll
         for (int i = 0; i < NR / 8; i++) acc[i] = 0;
@@ -235,10 +257,10 @@ struct RegsStep {
             constexpr int rb = b - (LB + 1);
             constexpr unsigned ch = cls_c<P, R>(rotl_c<NB>(1u << LB, PHI));
             unsigned TP[NC], TQ[NC], TE[NC];
-            branch_fields_paired<C, NC, ch>(s, T, TP);
+            branch_fields_paired<C, NC, ch>(s, T, TP, PD);
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                TQ[c] = COMP2 - TP[c];
+                TQ[c] = comp_of(TP[c]);
                 TE[c] = as_u32(as_v(TP[c]) - as_v(TQ[c]));  // t - t' per field (mod 2^16)
             }
             static_for<NR / 2>([&](auto I) {
@@ -250,8 +272,8 @@ struct RegsStep {
                 const u16x2 t = as_v(TP[cr]), tc = as_v(TQ[cr]);
                 if constexpr (SAT) {
                     const u16x2 m0 = madd<SAT>(A, t), m1 = madd<SAT>(B, tc), m2 = madd<SAT>(A, tc), m3 = madd<SAT>(B, t);
-                    M[r0] = acs_pk<SAT, (r0 & 7) + 1>(m0, m1, acc[r0 >> 3]);
-                    M[r1] = acs_pk<SAT, (r1 & 7) + 1>(m2, m3, acc[r1 >> 3]);
+                    M[r0] = acs_pk<SAT, (r0 & 7) + KB0>(m0, m1, acc[r0 >> 3]);
+                    M[r1] = acs_pk<SAT, (r1 & 7) + KB0>(m2, m3, acc[r1 >> 3]);
                 } else {
                     // modular family: everything is exact mod 2^16, so the two differences share A-B:
                     //   m0-m1 = (A-B) + (t-t'),  m2-m3 = (A-B) - (t-t')      (9 packed ops per butterfly pair instead of 10)
@@ -273,19 +295,19 @@ struct RegsStep {
             static_for<NR>([&](auto I) {
                 constexpr int r0 = decltype(I)::value;
                 constexpr unsigned cr = cls_c<P, R>(rotl_c<NB>((unsigned)r0 << (LB + 1), PHI));
-                const unsigned t = T[cr], tc = ((unsigned)C::bm_comp << 8) - t;
+                const unsigned t = T[cr], tc = SAT ? ((CQ1 - t) & 0xffffu) : COMP1 - t;
                 const u16x2 A = M[r0];
                 // broadcasting one field to both lanes of a packed add is an op_sel modifier, not an instruction
                 const u16x2 Alo = {A.x, A.x}, Ahi = {A.y, A.y};
                 const u16x2 lower = madd<SAT>(Alo, as_v(t | (tc << 16)));   // (m0, m2) = old[j] + (t, t')
                 const u16x2 upper = madd<SAT>(Ahi, as_v(tc | (t << 16)));   // (m1, m3) = old[j+H] + (t', t)
-                M[r0] = acs_pk<SAT, (r0 & 7) + 1>(lower, upper, acc[r0 >> 3]);
+                M[r0] = acs_pk<SAT, (r0 & 7) + KB0>(lower, upper, acc[r0 >> 3]);
             });
         } else {
             // ---- lane stage: partner register lives in lane ^ (1<<b) of the same quad
             constexpr unsigned ch = cls_c<P, R>(rotl_c<NB>(1u << LB, PHI));
             unsigned TP[NC], TQ[NC];
-            branch_fields_paired<C, NC, ch>(s, T, TP);
+            branch_fields_paired<C, NC, ch>(s, T, TP, PD);
             // The X lane of a pair holds old[j] and will hold new[2j] = ACS(old[j]+t, old[j+H]+t'); the Y lane holds
             // old[j+H] and will hold new[2j+1] = ACS(old[j]+t', old[j+H]+t).  Both lanes fetch old[j] and old[j+H] with two
             // broadcasting DPP moves, and the lane-dependent choice between t and t' is made once per class and step
@@ -294,7 +316,7 @@ struct RegsStep {
             unsigned TL[NC], TU[NC];
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                TQ[c] = COMP2 - TP[c];
+                TQ[c] = comp_of(TP[c]);
                 TL[c] = isY ? TQ[c] : TP[c];
                 TU[c] = isY ? TP[c] : TQ[c];
             }
@@ -306,7 +328,7 @@ struct RegsStep {
                 const u16x2 up_src = dpp_quad<YSEL>(M[r0]);  // old[j+H]
                 const u16x2 lower = madd<SAT>(lo_src, as_v(TL[cr]));
                 const u16x2 upper = madd<SAT>(up_src, as_v(TU[cr]));
-                M[r0] = acs_pk<SAT, (r0 & 7) + 1>(lower, upper, acc[r0 >> 3]);
+                M[r0] = acs_pk<SAT, (r0 & 7) + KB0>(lower, upper, acc[r0 >> 3]);
             });
         }
 
@@ -314,20 +336,22 @@ struct RegsStep {
         if constexpr (G::NRW == 16) {
 #pragma unroll
             for (int w = 0; w < G::DW; w++) {
-                const unsigned v = (acc[2 * w] >> 1) | (acc[2 * w + 1] << 7);  // accumulators use bits 1..8 / 17..24
+                // accumulators use bits KB0..KB0+7 / 16+KB0..16+KB0+7
+                const unsigned v = (acc[2 * w] >> KB0) | (acc[2 * w + 1] << (8 - KB0));
                 words[w] = SAT ? ~v : v;
             }
         } else {
-            const unsigned v = ((acc[0] >> 1) & 0xffu) | ((acc[0] >> 9) & 0xff00u);
+            const unsigned v = ((acc[0] >> KB0) & 0xffu) | ((acc[0] >> (8 + KB0)) & 0xff00u);
             words[0] = SAT ? (v ^ 0xffffu) : v;
         }
 
-        // ---- renormalisation (spiral only): if new[0] > thr subtract the frame minimum, saturating
+        // ---- renormalisation (spiral only): if new[0] > thr the frame minimum is owed (subtracted by the next step's branch
+        // metrics; the reference subtracts it here, saturating -- never clamping, it is the minimum)
         if constexpr (C::renorm) {
             unsigned v0 = as_u32(M[0]) & 0xffffu;  // state 0 always sits at position 0: register 0, low field, lane 0
             if constexpr (LB == 1) v0 = (unsigned)__builtin_amdgcn_mov_dpp((int)v0, 0xA0, 0xf, 0xf, true);  // [0,0,2,2]
             if constexpr (LB == 2) v0 = (unsigned)__builtin_amdgcn_mov_dpp((int)v0, 0x00, 0xf, 0xf, true);  // [0,0,0,0]
-            const bool fire = v0 > (((unsigned)C::renorm_thr << 8) | 0xffu);  // spiral47.cpp:313
+            const bool fire = v0 > field_from<true>(C::renorm_thr);  // spiral47.cpp:313
             // A single serial min chain makes every v_pk_min_u16 wait for its predecessor (hipcc pads it with s_nop).  A
             // pairwise tree is what hipcc schedules best around the survivors' arithmetic for every geometry except
             // K=7 r=1/2, where four interleaved chains (fewer live values) win -- measured, update ms tree / chains:
@@ -353,9 +377,7 @@ struct RegsStep {
             mn = __builtin_elementwise_min(mn, sw);
             if constexpr (LB >= 1) mn = __builtin_elementwise_min(mn, dpp_xor<0>(mn));
             if constexpr (LB >= 2) mn = __builtin_elementwise_min(mn, dpp_xor<1>(mn));
-            const u16x2 amt = as_v(fire ? (as_u32(mn) & 0xff00ff00u) : 0u);
-#pragma unroll
-            for (int i = 0; i < NR; i++) M[i] = __builtin_elementwise_sub_sat(M[i], amt);  // subs_epu8  spiral47.cpp:327-330
+            pend = fire ? (as_u32(mn) & 0xff80ff80u) : 0u;  // subs_epu8  spiral47.cpp:327-330, one step later
         }
     }
 };
@@ -412,7 +434,7 @@ struct RingSink {
 // one period = NB consecutive trellis steps at phases 0..NB-1; GUARD: skip steps outside [row0,row_end)
 template <class C, class P, int LB, bool GUARD, class Sink, int NR_, int SW_>
 __device__ __forceinline__ void run_period(u16x2 (&M)[NR_], const unsigned (&cur)[SW_], int rbase, int row0, int row_end,
-                                           unsigned lam, Sink &sink) {
+                                           unsigned lam, Sink &sink, unsigned &pend) {
     using G = RegsCfg<C, P, LB>;
     using S = RegsStep<C, P, LB>;
     constexpr int R = G::R, DW = G::DW;
@@ -427,7 +449,7 @@ __device__ __forceinline__ void run_period(u16x2 (&M)[NR_], const unsigned (&cur
                 sraw[q] = (cur[idx >> 2] >> (8 * (idx & 3))) & 255u;
             }
             unsigned words[DW];
-            S::template run<PHI>(M, sraw, lam, words);
+            S::template run<PHI>(M, sraw, lam, words, pend);
 #pragma unroll
             for (int w = 0; w < DW; w++) sink.put(w, words[w]);
             sink.next_row(r);
@@ -470,6 +492,7 @@ __device__ __forceinline__ void acs_regs_body(const AcsRegsArgs &a) {
     const long lim = (long)a.nsteps * R;
     const bool aligned = ((reinterpret_cast<uintptr_t>(a.syms) | a.sym_stride) & 3) == 0 && ((phi0 * R) & 3) == 0;
     GlobalSink<DW, G::WBYTES> sink{a.dec + ((wave * a.cap_rows + row0) * (long)DW * 64 + lane) * G::WBYTES};
+    unsigned pend = 0;  // saturating family: the minimum the last renormalisation owes (RegsStep::run)
 
     int rbase = row0 - phi0;
     while (rbase < row_end) {
@@ -478,7 +501,7 @@ __device__ __forceinline__ void acs_regs_body(const AcsRegsArgs &a) {
             // slow period: partial head / tail, or unaligned symbols
             unsigned cur[SW];
             load_period_guarded<SW>(sp, (long)(rbase - row0) * R, lim, cur);
-            run_period<C, P, LB, true>(M, cur, rbase, row0, row_end, lam, sink);
+            run_period<C, P, LB, true>(M, cur, rbase, row0, row_end, lam, sink, pend);
             rbase += NB;
             continue;
         }
@@ -496,7 +519,7 @@ __device__ __forceinline__ void acs_regs_body(const AcsRegsArgs &a) {
         for (int i = 0; i < nfull; i++) {
             const long noff = off + NB * R < last_off ? off + NB * R : last_off;  // clamped: no branch around the load
             load_period_fast<SW>(sp, noff, nxt);
-            run_period<C, P, LB, false>(M, cur, rbase, row0, row_end, lam, sink);
+            run_period<C, P, LB, false>(M, cur, rbase, row0, row_end, lam, sink, pend);
 #pragma unroll
             for (int w = 0; w < SW; w++) cur[w] = nxt[w];
             off += NB * R;
@@ -512,7 +535,7 @@ __device__ __forceinline__ void acs_regs_body(const AcsRegsArgs &a) {
             for (int h = 0; h < 2; h++) {
                 const unsigned p = ((unsigned)r0 << (LB + 1)) | ((unsigned)h << LB) | lam;
                 const unsigned st = phie == 0 ? p : (((p << phie) | (p >> (NB - phie))) & (G::N - 1));
-                gm[st] = (int16_t)field_to(as_u32(M[r0]) >> (16 * h));
+                gm[st] = (int16_t)(field_to<G::SAT>(as_u32(M[r0]) >> (16 * h)) - (int)((pend >> 7) & 0xffu));
             }
         }
     }
@@ -589,6 +612,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const long lim = (long)T * R;
     const bool aligned = ((reinterpret_cast<uintptr_t>(a.syms) | a.sym_stride) & 3) == 0;
     RingSink<DW, WB, RING> sink{ring + lane * WB, 0};
+    unsigned pend = 0;
     unsigned char *out = a.data + fc * (long)a.data_stride;
     const unsigned nblocks = (a.nbits + BLOCK - 1) / BLOCK;
     unsigned nextb = 0;
@@ -709,7 +733,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         for (int i = 0; i < nfull; i++) {
             const long noff = off + NB * R < last_off ? off + NB * R : last_off;  // clamped: no branch around the load
             load_period_fast<SW>(sp, noff, nxt);
-            run_period<C, P, LB, false>(M, cur, rbase, 0, T, lam, sink);
+            run_period<C, P, LB, false>(M, cur, rbase, 0, T, lam, sink, pend);
 #pragma unroll
             for (int w = 0; w < SW; w++) cur[w] = nxt[w];
             off += NB * R;
@@ -720,7 +744,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     while (rbase < T) {  // the last partial period, or symbols that are not dword aligned
         unsigned cur[SW];
         load_period_guarded<SW>(sp, (long)rbase * R, lim, cur);
-        run_period<C, P, LB, true>(M, cur, rbase, 0, T, lam, sink);
+        run_period<C, P, LB, true>(M, cur, rbase, 0, T, lam, sink, pend);
         rbase += NB;
         emit_ready(rbase < T ? rbase : T);
     }
