@@ -36,6 +36,7 @@ namespace wave7 {
 
 constexpr int K = 7, NB = 6;
 constexpr unsigned N = 64, H = 32;
+static_assert(NB == K - 1 && N == 1u << NB && H == N / 2, "one state per lane");
 constexpr int BLK = 48;        // steps per unrolled block = 8 periods; their rows leave as one 384-byte store
 constexpr int THREADS = 256;   // wave 0 walks the trellis, waves 1..3 fill the branch-metric table of the next chunk
 constexpr int TBL_BYTES = 30720;  // per buffer: CH steps x 2^R classes x 8 bytes, CH a multiple of BLK
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(THREADS) void acs_wave_kernel(Args a) {
 namespace k9 {
 constexpr int K = 9, NB = 8;
 constexpr unsigned N = 256, H = 128;
+static_assert(NB == K - 1 && N == 1u << NB && H == N / 2, "four states per lane");
 __host__ __device__ constexpr unsigned rotl8(unsigned x, int s) {
     s %= NB;
     return s == 0 ? x : (((x << s) | (x >> (NB - s))) & (N - 1u));
