@@ -1,0 +1,109 @@
+"""Handle lifecycle on the device: everything a handle allocates -- metrics, decision histories of every pipeline slot, staging
+buffers of the host-pointer calls, the segment-parallel chainback's scratch, the windowed decode's ring, the run-time built
+module of a non-harness polynomial, internal streams and events -- goes back when the handle is deleted
+(delete_viterbi27_sse2 and friends free their one allocation, viterbi27_sse2.cpp:107-113; a drop-in must not do worse over the
+thousands of create/delete cycles a long-running caller makes)."""
+import numpy as np
+import pytest
+import torch
+
+from common import frames, spec_of
+from ka9q_viterbi_comparison_amd import HipViterbi, codes as C
+from ka9q_viterbi_comparison_amd import VARIANT_AUTO, VARIANT_HBM, VARIANT_LDS, VARIANT_REGS, VARIANT_WAVE
+
+pytestmark = pytest.mark.gpu
+
+
+def _use(dec, code, nframes, B, syms, host):
+    spec = spec_of(code)
+    steps = B * 8 + spec.K - 1
+    dec.reset()
+    if host:
+        dec.update(syms, nbits=steps)
+        data, _ = dec.chainback(B * 8)
+        return data
+    d_syms = torch.from_numpy(syms).cuda()
+    d_out = torch.zeros(nframes * B, dtype=torch.uint8, device="cuda")
+    dec.update(d_syms, nbits=steps)
+    dec.chainback(B * 8, out=d_out)
+    dec.sync()
+    return d_out.cpu().numpy().reshape(nframes, B)
+
+
+# (code, nframes, payload bytes, variant, pipeline depth): every allocation path of vhip_create / set_variant / set_pipeline_depth
+CASES = [
+    (C.KA9Q27, 1, 64, VARIANT_AUTO, 1),      # wave kernel, one frame
+    (C.KA9Q27, 5000, 16, VARIANT_AUTO, 2),   # register kernel, two decision histories
+    (C.SPIRAL47, 70, 32, VARIANT_LDS, 1),    # natural rows
+    (C.KA9Q29, 3, 40, VARIANT_WAVE, 3),
+    (C.SPIRAL49, 2100, 8, VARIANT_REGS, 2),
+    (C.KA9Q615, 3, 24, VARIANT_AUTO, 2),     # segment-parallel chainback scratch per slot
+    (C.SPIRAL615, 70, 8, VARIANT_AUTO, 1),
+    (C.KA9Q224, 1, 8, VARIANT_AUTO, 1),      # tiled passes, pinned report words
+    (C.KA9Q224, 1, 6, VARIANT_HBM, 1),
+]
+
+
+@pytest.mark.timeout(600)
+def test_create_use_delete_returns_the_device_memory():
+    torch.cuda.init()
+    inputs = []
+    for code, nframes, B, variant, depth in CASES:
+        payload, syms = frames(code, 11, nframes, B)
+        inputs.append((payload, np.ascontiguousarray(syms)))
+
+    def cycle(check):
+        for (code, nframes, B, variant, depth), (payload, syms) in zip(CASES, inputs):
+            spec = spec_of(code)
+            steps = B * 8 + spec.K - 1
+            for host in (False, True):
+                dec = HipViterbi(spec.name, steps, nframes=nframes, variant=variant, pipeline_depth=depth)
+                out = _use(dec, code, nframes, B, syms, host)
+                if check and spec.K != 24:  # K=24: the payload comes out of the nbits+K-1 call, not checked here
+                    assert np.array_equal(out[:, :B], payload), (code, host)
+                assert dec.device_bytes > 0
+                dec.close()
+        # a non-harness polynomial: fast kernel built (or fetched from the cache) at create time, module unloaded with the handle
+        dec = HipViterbi("27", 64 + 6, nframes=3000, poly=(0o133, 0o171))
+        dec.close()
+        # the fused windowed decode's ring (K=15)
+        dec = HipViterbi("615", 256 + 14, nframes=2, pipeline_depth=2)
+        if dec.window is not None:
+            d_syms = torch.zeros(2 * (256 + 14) * 6, dtype=torch.uint8, device="cuda")
+            d_out = torch.zeros(2 * 32, dtype=torch.uint8, device="cuda")
+            dec.decode_windowed(d_syms, 256, d_out)
+            dec.sync()
+        dec.close()
+        torch.cuda.synchronize()
+
+    cycle(check=True)  # first use: module loads, the JIT cache, lazily created runtime state
+    cycle(check=False)
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(12):
+        cycle(check=False)
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    # 12 rounds x 20 handles: one buffer of 1.4 MiB leaked per round would trip this (a K=24 handle holds 32 MiB of metrics, the
+    # 5000-frame case 5 MiB of decisions per slot)
+    assert free0 - free1 < 16 << 20, f"device memory not returned: {free0 - free1} bytes over 12 rounds"
+
+
+def test_delete_with_work_in_flight():
+    """delete while the handle's kernels are still queued: the library drains its streams first (nothing the caller enqueued
+    later may see freed buffers reused)."""
+    code, nframes, B = C.KA9Q29, 4000, 64
+    spec = spec_of(code)
+    steps = B * 8 + spec.K - 1
+    payload, syms = frames(code, 3, nframes, B)
+    d_syms = torch.from_numpy(np.ascontiguousarray(syms)).cuda()
+    d_out = torch.zeros(nframes * B, dtype=torch.uint8, device="cuda")
+    for depth in (1, 2):
+        dec = HipViterbi(spec.name, steps, nframes=nframes, pipeline_depth=depth)
+        for _ in range(3):
+            dec.reset()
+            dec.update(d_syms, nbits=steps)
+            dec.chainback(B * 8, out=d_out)
+        dec.close()  # no sync before
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy().reshape(nframes, B), payload)
