@@ -107,3 +107,49 @@ def test_delete_with_work_in_flight():
         dec.close()  # no sync before
         torch.cuda.synchronize()
         assert np.array_equal(d_out.cpu().numpy().reshape(nframes, B), payload)
+
+
+@pytest.mark.timeout(600)
+def test_handles_on_concurrent_host_threads():
+    """One handle per host thread, all threads at once (distinct handles are independent; the reference's decoders
+    share one process-global branch table, ours keep theirs per handle): blocking host-pointer calls of four different kernel
+    families interleave on the device, two threads create handles for the same non-harness polynomial at the same moment (one
+    run-time build, one cache entry), and every decode is the payload."""
+    import threading
+
+    jobs = [(C.KA9Q27, 1, 128, None), (C.SPIRAL47, 3000, 16, None), (C.KA9Q615, 2, 32, None), (C.KA9Q224, 1, 8, None),
+            (C.KA9Q27, 2100, 16, (0o135, 0o147)), (C.KA9Q27, 2500, 8, (0o135, 0o147))]  # register kernels: built at run time
+    errors = []
+    start = threading.Barrier(len(jobs))
+
+    def worker(code, nframes, B, poly):
+        try:
+            spec = spec_of(code)
+            steps = B * 8 + spec.K - 1
+            from ka9q_viterbi_comparison_amd.decoder import gen_frames_host
+
+            payload, syms = gen_frames_host(spec, 5 + code, 0, nframes, B, C.HARD_AMP_Q16, 0, poly=poly)
+            syms = np.ascontiguousarray(syms)
+            start.wait()
+            for it in range(12):
+                dec = HipViterbi(spec.name, steps, nframes=nframes, poly=poly)
+                for _ in range(3):
+                    dec.reset()
+                    dec.update(syms, nbits=steps)
+                    if spec.K == 24:  # the payload comes out of the nbits+K-1 call (SURVEY.md §0.4)
+                        data, _ = dec.chainback(steps)
+                    else:
+                        data, _ = dec.chainback(B * 8)
+                    if not np.array_equal(data[:, :B], payload):
+                        errors.append(f"code {code} x {nframes}: wrong bytes in iteration {it}")
+                        return
+                dec.close()
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append(f"code {code} x {nframes}: {type(e).__name__}: {e}")
+
+    threads = [threading.Thread(target=worker, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
