@@ -37,6 +37,9 @@ thread_local unsigned g_fail_count = 0;
 
 int fail(const char *what, hipError_t e = hipSuccess) {
     char buf[512];
+    // a failed runtime call also stays behind as the thread's "last error", and the next kernel launch -- of any handle -- would
+    // read it back from hipGetLastError() as its own: one refused hipMalloc must not fail the healthy handle created after it
+    (void)hipGetLastError();
     if (e != hipSuccess)
         snprintf(buf, sizeof(buf), "viterbi_hip: %s: %s", what, hipGetErrorString(e));
     else

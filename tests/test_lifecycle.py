@@ -153,3 +153,42 @@ def test_handles_on_concurrent_host_threads():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_allocation_failure_is_an_error_not_a_crash():
+    """A decision history that cannot fit the card: the call that needs it fails with a message (the reference: create returns
+    NULL when its posix_memalign fails, viterbi27_sse2.cpp:60-66; here the history is allocated by the first update, so that a
+    handle used only for the fused windowed decode never holds one), nothing is left behind, and the next handle works."""
+    from ka9q_viterbi_comparison_amd._lib import VhipError, last_error
+
+    free0, total = torch.cuda.mem_get_info()
+    for name, steps, nframes in (("29", 1 << 20, 1 << 20), ("615", 1 << 16, 1 << 18), ("27", (1 << 31) - 64, 70000)):
+        try:
+            dec = HipViterbi(name, steps, nframes=nframes)
+        except VhipError:
+            continue
+        d_syms = torch.zeros(nframes * dec.R, dtype=torch.uint8, device="cuda")
+        assert dec._lib.vhip_update_dev(dec._h, d_syms.data_ptr(), 1) != 0, (name, "an update without a history succeeded")
+        assert "alloc" in last_error().lower() or "memory" in last_error().lower(), last_error()
+        dec.close()
+        del d_syms
+    # a second decision history that does not fit: the call fails, the handle stays at depth 1 (vhip_set_pipeline_depth frees
+    # what it had allocated for the slot)
+    spec = C.CODES["29"]
+    steps = 8 * 8 + spec.K - 1
+    per_frame = (steps + spec.K - 1) * 32  # rows of 2^(K-1)/8 bytes
+    nframes = int(free0 * 0.45 / per_frame)
+    dec = HipViterbi("29", steps, nframes=nframes)
+    assert dec._lib.vhip_set_pipeline_depth(dec._h, 2) != 0
+    assert dec.pipeline_depth == 1
+    dec.close()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, f"a failed create kept {free0 - free1} bytes"
+    payload, syms = frames(C.KA9Q27, 1, 3, 16)
+    dec = HipViterbi("27", 16 * 8 + 6, nframes=3)
+    dec.reset()
+    dec.update(np.ascontiguousarray(syms), nbits=16 * 8 + 6)
+    data, _ = dec.chainback(16 * 8)
+    assert np.array_equal(data, payload)
+    dec.close()
