@@ -171,6 +171,9 @@ int init_start_of(int code) {
 
 // a handle is bound to the device that was current at create(); callers may since have switched devices
 int use_device(const vhip_decoder *p) {
+    // every entry point comes through here first: drop whatever "last error" another library's failed call left in this thread,
+    // or the first kernel launch below would report it as its own (launch_* return hipGetLastError())
+    (void)hipGetLastError();
     int cur = -1;
     if (hipGetDevice(&cur) == hipSuccess && cur == p->device) return 0;
     HIP_TRY(hipSetDevice(p->device));
@@ -621,6 +624,7 @@ int vhip_code_K(int code) { return vh::code_info(code).K; }
 int vhip_code_R(int code) { return vh::code_info(code).R; }
 
 vhip_decoder *vhip_create(int code, const int *poly, int len, int nframes) {
+    (void)hipGetLastError();  // see use_device
     const vh::CodeInfo ci = vh::code_info(code);
     if (ci.K == 0) {
         fail("create: unknown code");
@@ -1370,12 +1374,14 @@ int vhip_gen_frames_dev(int K, int R, const int *poly, uint64_t seed, uint64_t f
                         int amp_q16, int noise_q12, unsigned char *d_payload, unsigned char *d_syms, void *stream) {
     if (K < 2 || K > 32 || R < 1 || R > 8 || !poly || nframes < 0 || payload_bytes < 0) return fail("gen_frames: bad arguments");
     if (nframes == 0) return 0;
+    (void)hipGetLastError();  // see use_device
     HIP_TRY(vh::launch_gen_frames(K, R, poly, seed, frame0, nframes, payload_bytes, amp_q16, noise_q12, d_payload, d_syms,
                                   reinterpret_cast<hipStream_t>(stream)));
     return 0;
 }
 
 long long vhip_count_bit_errors_dev(const unsigned char *d_a, const unsigned char *d_b, size_t nbytes, void *stream) {
+    (void)hipGetLastError();  // see use_device
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned long long *d_count = nullptr;
     if (hipMalloc(reinterpret_cast<void **>(&d_count), sizeof(*d_count)) != hipSuccess) return fail("count_bit_errors: alloc");

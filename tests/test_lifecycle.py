@@ -192,3 +192,42 @@ def test_allocation_failure_is_an_error_not_a_crash():
     data, _ = dec.chainback(16 * 8)
     assert np.array_equal(data, payload)
     dec.close()
+
+
+def test_errors_of_other_calls_do_not_leak_into_a_decode():
+    """(1) Another library's failed runtime call leaves a 'last error' in the thread; the decoder's launches must not report it as
+    theirs.  (2) The decoder's own refused call -- an update beyond the handle's capacity -- is an error for that call only: the
+    same handle decodes correctly afterwards."""
+    import ctypes
+
+    from ka9q_viterbi_comparison_amd._lib import VhipError
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    code, nframes, B = C.SPIRAL47, 5, 24
+    spec = spec_of(code)
+    steps = B * 8 + spec.K - 1
+    payload, syms = frames(code, 9, nframes, B)
+    syms = np.ascontiguousarray(syms)
+    dec = HipViterbi(spec.name, steps, nframes=nframes)
+
+    def decode_ok():
+        dec.reset()
+        dec.update(syms, nbits=steps)
+        data, _ = dec.chainback(B * 8)
+        assert np.array_equal(data, payload)
+
+    decode_ok()
+    ptr = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(1 << 60)) != 0  # refused: stays behind as the thread's last error
+    decode_ok()
+    assert hip.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(1 << 60)) != 0
+    other = HipViterbi("615", 64 + 14, nframes=2)  # create launches the metric initialisation
+    other.close()
+    # beyond capacity: an error, nothing written, the handle still good
+    too_many = np.zeros((nframes, (steps + 40) * spec.R), dtype=np.uint8)
+    dec.reset()
+    with pytest.raises(VhipError):
+        dec.update(too_many, nbits=steps + 40)
+    assert dec.rows_written <= steps
+    decode_ok()
+    dec.close()
