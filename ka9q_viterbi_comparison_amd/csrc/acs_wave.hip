@@ -170,11 +170,13 @@ __device__ __forceinline__ void renormalise(unsigned &M, Lazy &lz) {
         }
     }
 }
-// off grows by at most 63 per step; once per block of steps it is folded back into the registers long before it can wrap
+// off grows by at most 63 per step; once per block of steps it is folded back into the registers long before it can wrap (at
+// 2^20 -- every ~17 000 steps or more -- rather than near 2^32, so that frames of ordinary length take this path too and the
+// tests reach it: tests/test_full_size.py::test_one_very_long_frame)
 template <class C, int NM>
 __device__ __forceinline__ void fold_offset(unsigned (&M)[NM], Lazy &lz) {
     if constexpr (C::renorm) {
-        if (lz.off > (1u << 30)) {
+        if (lz.off > (1u << 20)) {
 #pragma unroll
             for (int r = 0; r < NM; r++) M[r] -= lz.off;
             lz.off = 0;

@@ -278,3 +278,36 @@ def test_bench_chunked_shard(name, frames, chunk, bits):
         assert np.array_equal(got[f], oracle_frame(spec, syms[f], steps, bits)), f
     assert st["bit_errors"] == count_bit_errors_dev(d_out, shard.d_payload, frames * bits // 8)
     shard.close()
+
+
+@pytest.mark.parametrize("name", ["27", "47", "29", "49", "spiral27", "spiral29"])
+def test_one_very_long_frame(name):
+    """One frame of 600 000 bits through the handle's own choice for a single frame (the wave-per-frame kernels): hundreds of
+    branch-metric table chunks, byte offsets past 2^22 in a frame's symbols, and -- spiral arithmetic -- the lazy offset of the
+    saturating metrics folded back into the registers dozens of times (acs_wave.hip fold_offset).  Every decoded byte, the
+    final metrics and a sample of decision rows against the oracle; then the same bytes from the register kernel."""
+    from common import frames
+
+    spec = C.CODES[name]
+    B = 75000
+    steps = B * 8 + spec.K - 1
+    steps -= steps % 2 if spec.family.startswith("spiral") else 0
+    _, syms = frames(spec.code, 4242, 1, B, spec.ebn0_db)
+    syms = np.ascontiguousarray(syms[:, :steps * spec.R])
+    o = OracleDecoder(spec.code, spec.poly, steps)
+    o.update(syms[0], steps)
+    ref_bytes = o.chainback(B * 8)[0]
+    ref_metrics = o.metrics()
+    ref_rows = o.rows(steps)
+    o.close()
+    got = None
+    for variant in (0, VARIANT_REGS):
+        dec = HipViterbi(name, steps, nframes=1, variant=variant)
+        dec.reset()
+        dec.update(syms, nbits=steps)
+        data, _ = dec.chainback(B * 8)
+        assert np.array_equal(data[0], ref_bytes), (name, variant)
+        assert np.array_equal(dec.metrics(0), ref_metrics), (name, variant)
+        for row0 in (0, 4999, steps // 2, steps - 700):
+            assert np.array_equal(dec.decision_rows(0, row0, 600), ref_rows[row0:row0 + 600]), (name, variant, row0)
+        dec.close()
