@@ -231,3 +231,40 @@ def test_errors_of_other_calls_do_not_leak_into_a_decode():
     assert dec.rows_written <= steps
     decode_ok()
     dec.close()
+
+
+@pytest.mark.parametrize("depth", [1, 2])
+def test_one_handle_through_every_kernel_family(depth):
+    """vhip_set_variant between decodes of ONE handle: the decision history, metrics and scratch of the handle serve every kernel
+    family in turn (their row layouts differ; the history is sized once), in both orders, and each decode is the oracle's."""
+    from ka9q_viterbi_comparison_amd._lib import check
+    from oracle_lib import OracleDecoder
+
+    for code, nframes, B, variants in (
+        (C.KA9Q27, 3, 40, [VARIANT_WAVE, VARIANT_REGS, VARIANT_LDS, VARIANT_REGS | (2 << 8), VARIANT_WAVE, VARIANT_LDS, VARIANT_AUTO]),
+        (C.SPIRAL47, 70, 24, [VARIANT_REGS, VARIANT_WAVE, VARIANT_LDS, VARIANT_REGS | (3 << 8), VARIANT_AUTO]),
+        (C.KA9Q29, 5, 32, [VARIANT_LDS, VARIANT_WAVE, VARIANT_REGS, VARIANT_WAVE]),
+        (C.SPIRAL49, 2, 16, [VARIANT_WAVE, VARIANT_LDS, VARIANT_REGS, VARIANT_AUTO]),
+        (C.KA9Q615, 2, 16, [VARIANT_REGS, VARIANT_LDS, VARIANT_REGS]),
+    ):
+        spec = spec_of(code)
+        steps = B * 8 + spec.K - 1
+        _, syms = frames(code, 50 + code, nframes, B, ebn0_db=spec.ebn0_db)
+        syms = np.ascontiguousarray(syms[:, :steps * spec.R])
+        refs = []
+        for f in range(nframes):
+            o = OracleDecoder(code, spec.poly, steps)
+            o.update(syms[f], steps)
+            refs.append((o.chainback(B * 8)[0], o.metrics(), o.rows(steps)))
+            o.close()
+        dec = HipViterbi(spec.name, steps, nframes=nframes, pipeline_depth=depth)
+        for v in variants:
+            dec.reset()
+            check(dec._lib.vhip_set_variant(dec._h, v), "vhip_set_variant")
+            dec.update(syms, nbits=steps)
+            data, _ = dec.chainback(B * 8)
+            for f in range(nframes):
+                assert np.array_equal(data[f], refs[f][0]), (code, v, f)
+                assert np.array_equal(dec.metrics(f), refs[f][1]), (code, v, f)
+                assert np.array_equal(dec.decision_rows(f, 0, steps), refs[f][2]), (code, v, f)
+        dec.close()
