@@ -63,3 +63,32 @@ def test_unaligned_symbol_and_output_pointers(code, nframes, variant):
             o.update(syms[f], steps)
             assert np.array_equal(o.chainback(nbits)[0], results[0][0][f])
             o.close()
+
+
+@pytest.mark.parametrize("name,nframes,nbits", [("27", 70, 1000), ("27", 3, 61), ("47", 65, 400), ("49", 17, 333), ("615", 3, 300)])
+def test_unaligned_pointers_fused_windowed_decode(name, nframes, nbits):
+    """The fused sliding-window decode stores four decoded bytes at a time where the output allows it (K=7 steady state): the
+    same bytes must come out at every output offset, nothing outside the window may be written."""
+    spec = C.CODES[name]
+    steps = nbits + spec.K - 1  # the spiral decoders drop an odd last step themselves (spiral47.cpp:536-538)
+    B = (nbits + 7) // 8
+    _, syms = frames(spec.code, 5, nframes, B, ebn0_db=spec.ebn0_db)
+    syms = np.ascontiguousarray(syms[:, :steps * spec.R])
+    flat = torch.from_numpy(syms.reshape(-1))
+    nbytes = (nbits + 7) // 8
+    results = []
+    for off_in, off_out in ((0, 0), (1, 1), (2, 3), (3, 2)):
+        buf = torch.zeros(flat.numel() + 8, dtype=torch.uint8, device="cuda")
+        buf[off_in:off_in + flat.numel()] = flat.cuda()
+        obuf = torch.full((nframes * nbytes + 8,), 0xA5, dtype=torch.uint8, device="cuda")
+        d_out = obuf[off_out:off_out + nframes * nbytes]
+        dec = HipViterbi(name, steps, nframes=nframes)
+        assert dec.window is not None
+        dec.decode_windowed(buf[off_in:off_in + flat.numel()], nbits, d_out)
+        dec.sync()
+        guard = obuf.cpu().numpy()
+        assert (guard[:off_out] == 0xA5).all() and (guard[off_out + nframes * nbytes:] == 0xA5).all()
+        results.append(d_out.cpu().numpy().copy())
+        dec.close()
+    for r in results[1:]:
+        assert np.array_equal(r, results[0])
