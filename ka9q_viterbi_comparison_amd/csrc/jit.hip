@@ -64,8 +64,8 @@ std::string source_dir() {
 
 std::string compiler() {
     if (const char *e = getenv("VHIP_HIPCC")) return e;
-    std::string root = getenv("ROCM_PATH") ? getenv("ROCM_PATH") : "/opt/rocm";
-    return root + "/bin/hipcc";
+    const char *rocm = getenv("ROCM_PATH");
+    return std::string(rocm ? rocm : "/opt/rocm") + "/bin/hipcc";
 }
 
 constexpr unsigned long long FNV_BASIS = 0xCBF29CE484222325ull, FNV_PRIME = 0x100000001B3ull;  // as tools/kernel_hash.py
