@@ -268,3 +268,34 @@ def test_one_handle_through_every_kernel_family(depth):
                 assert np.array_equal(dec.metrics(f), refs[f][1]), (code, v, f)
                 assert np.array_equal(dec.decision_rows(f, 0, steps), refs[f][2]), (code, v, f)
         dec.close()
+
+
+@pytest.mark.parametrize("name,variants", [("27", (0, 1, 2, 6)), ("47", (0, 2, 6)), ("29", (0, 1, 2, 6)), ("49", (0, 6)), ("615", (0, 1)), ("224", (0,))])
+def test_chainback_beyond_what_was_fed(name, variants):
+    """A chainback over more bits than steps were fed since the last init -- or than the handle can hold -- is a caller's bug the
+    reference answers with whatever its decision array holds (stale rows of the previous frame, or memory past the array,
+    viterbi27_sse2.cpp:97-103).  Here it is safe and defined: rows never written read as zero decisions, nothing is read
+    outside the history, no error is raised, and the handle decodes correctly afterwards."""
+    spec = C.CODES[name]
+    for v in variants:
+        for nframes in ((1,) if spec.K == 24 else (1, 70)):
+            B = 4 if spec.K == 24 else 40
+            steps = B * 8 + spec.K - 1
+            payload, syms = frames(spec.code, 3, nframes, B)
+            syms = np.ascontiguousarray(syms)
+            nb = steps if spec.K == 24 else B * 8
+            dec = HipViterbi(name, steps, nframes=nframes, variant=v)
+            dec.reset()
+            dec.update(syms, nbits=steps)
+            first, _ = dec.chainback(nb)
+            assert np.array_equal(first[:, :B], payload)
+            dec.reset()
+            dec.update(np.ascontiguousarray(syms[:, :16 * spec.R]), nbits=16)
+            dec.chainback(nb)                                          # more bits than steps fed since the init
+            dec.chainback(steps if spec.K == 24 else B * 8 + 5000)     # and more than the handle holds
+            assert dec.status == 0
+            dec.reset()
+            dec.update(syms, nbits=steps)
+            again, _ = dec.chainback(nb)
+            assert np.array_equal(again, first), (name, v, nframes)
+            dec.close()
