@@ -10,8 +10,9 @@
 //  * The N = 2^(K-1) metrics of a frame are 16-bit fields packed two per VGPR (v_pk_* integer ops):
 //    N/(2L) registers per lane.  u8-modular metrics (ka9q) sit in the HIGH byte of each field so that the
 //    16-bit wrap of v_pk_add_u16 IS the mod-256 wrap of _mm_add_epi8 and the sign of a 16-bit difference IS
-//    the sign of the 8-bit one; u8-saturating metrics (spiral) are (m<<8)|0xff so that the 16-bit clamp of
-//    v_pk_add_u16 ... clamp IS _mm_adds_epu8.
+//    the sign of the 8-bit one; u8-saturating metrics (spiral) are the signed field (m<<7)|0x7f so that the clamp of
+//    v_pk_add_i16 ... clamp IS _mm_adds_epu8 (255 <-> 0x7fff) even for a negative addend: the minimum a renormalisation
+//    (spiral47.cpp:313-331) subtracts is owed to the next step's branch metrics instead (RegsStep::run, `pend`).
 //  * In-place trellis with a rotating index map: new[2j] is written where old[j] lived and new[2j+1] where
 //    old[j+H] lived, so position p holds state rotl^t(p) before step t.  No metric ever moves between
 //    registers; the butterfly partner of step t differs in position bit (K-2 - t mod (K-1)), which is a
