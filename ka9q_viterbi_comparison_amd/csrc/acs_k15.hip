@@ -38,6 +38,7 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int K = 15, R = 6, NB = 14, N = 1 << NB;
+static_assert(NB == K - 1, "position bits");
 constexpr int THREADS = 128, NR = 64;
 #ifdef VH_JIT_KERNEL
 constexpr int POLY[6] = VH_JIT_POLY;  // runtime specialisation (jit.hip): the caller's polynomials
